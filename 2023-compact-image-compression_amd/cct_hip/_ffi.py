@@ -1,0 +1,131 @@
+"""ctypes binding of libcompact_hip.so (C ABI: include/compact_hip.h).
+
+No PyTorch, no CPU fallback: if the HIP library is missing or no gfx950 device is usable,
+every compute entry point raises -- the codec never silently runs somewhere else.
+"""
+import ctypes as C
+import os
+import zlib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcompact_hip.so")
+
+# error codes (include/compact_hip.h)
+OK, E_MAGIC, E_ZLIB, E_OVERFLOW, E_STREAM, E_SHAPE, E_CAP, E_NOMEM, E_DEVICE, E_ARG, E_MIXED = range(11)
+FLAG_FRACTAL, FLAG_SEGMENTATION, FLAG_DEFLATE, FLAG_SIGNED_SEG = 1, 2, 4, 8
+ST_Q7, ST_CAP, ST_OVERFLOW, ST_STREAM = 1, 2, 4, 8
+ROLE_PARTNER = 0xFF
+
+
+class CorruptStreamError(ValueError):
+    """Token stream a reference encoder cannot have produced (truncated / malformed)."""
+
+
+class DeviceError(RuntimeError):
+    """HIP library or gfx950 device unavailable."""
+
+
+class Header(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("bytes_per_channel", C.c_int32), ("fractal", C.c_int32),
+                ("segmentation", C.c_int32), ("deflate", C.c_int32)]
+
+
+class SliceStats(C.Structure):
+    _fields_ = [("n_short", C.c_uint32), ("n_full", C.c_uint32), ("n_jump", C.c_uint32),
+                ("n_difficult", C.c_uint32)]
+
+
+_SIGS = {
+    "cct_version": (C.c_int, []),
+    "cct_last_error": (C.c_char_p, []),
+    "cct_init": (C.c_int, [C.c_int]),
+    "cct_shutdown": (C.c_int, []),
+    "cct_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "cct_dev_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cct_dev_free": (C.c_int, [C.c_void_p]),
+    "cct_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cct_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cct_dev_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "cct_sync": (C.c_int, []),
+    "cct_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "cct_event_record": (C.c_int, [C.c_void_p]),
+    "cct_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "cct_event_destroy": (C.c_int, [C.c_void_p]),
+    "cct_curve_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "cct_payload_stride": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "cct_file_bound": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "cct_encode_payload_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cct_encode_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                   C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "cct_read_header": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(Header)]),
+    "cct_decode_payload_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p]),
+    "cct_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int,
+                                   C.c_size_t, C.c_void_p]),
+    "cct_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "cct_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcompact_hip.so once; raise DeviceError (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeviceError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                f"`make -C 2023-compact-image-compression_amd/csrc`; the codec has no CPU fallback")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise DeviceError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError here means header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if L.cct_version() != 1:
+            raise DeviceError("libcompact_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def last_error():
+    return lib().cct_last_error().decode("utf-8", "replace")
+
+
+def raise_for(rc):
+    """Map a CCT_E_* code to the exception the reference raises in the same situation."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == E_MAGIC:
+        raise ValueError("Image does not contain valid header")  # core.py:389
+    if rc == E_ZLIB:
+        raise zlib.error(msg)  # core.py:421
+    if rc == E_OVERFLOW:
+        raise OverflowError("int too big to convert")  # core.py:506/516 (int.to_bytes)
+    if rc == E_STREAM:
+        raise CorruptStreamError(msg)
+    if rc == E_SHAPE:
+        raise ValueError(msg)  # numpy reshape, core.py:245/429
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    if rc == E_DEVICE:
+        raise DeviceError(msg)
+    if rc in (E_ARG, E_MIXED):
+        raise ValueError(msg)
+    raise RuntimeError(f"libcompact_hip error {rc}: {msg}")
+
+
+def check(rc):
+    if rc != OK:
+        raise_for(rc)

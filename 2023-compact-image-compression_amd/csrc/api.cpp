@@ -1,0 +1,582 @@
+// Host side of libcompact_hip.so: device context, traversal-table cache, workspaces, the
+// DEFLATE/INFLATE stage (system libz on a host thread team -- the same library the reference
+// reaches through CPython's zlib module, core.py:340,421) and the extern "C" entry points
+// declared in include/compact_hip.h.
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/compact_hip.h"
+#include "cct_internal.h"
+
+namespace cct {
+bool gilbert_table(int width, int height, int32_t *out);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess)                                                                      \
+			return fail(CCT_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+	} while (0)
+
+struct DevBuf {  // grow-only device (or pinned host) buffer
+	void *p = nullptr;
+	size_t cap = 0;
+	bool pinned_host = false;
+	int ensure(size_t bytes)
+	{
+		if (bytes <= cap) return CCT_OK;
+		release();
+		const size_t want = bytes + bytes / 8 + 4096;
+		hipError_t e = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; cap = 0; return fail(CCT_E_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); }
+		cap = want;
+		return CCT_OK;
+	}
+	void release()
+	{
+		if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); }
+		p = nullptr; cap = 0;
+	}
+};
+
+struct Context {
+	bool ready = false;
+	pid_t pid = 0;
+	int device = -1;
+	hipStream_t stream = nullptr;
+	std::map<std::pair<int, int>, int32_t *> luts;  // (width,height) -> device traversal table
+	// encode workspaces
+	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
+	// decode workspaces
+	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images;
+	DevBuf h_stage;  // pinned host staging (payloads)
+	int zlib_threads = 0;
+	int wg_threads = 1024;
+};
+
+Context g_ctx;
+std::mutex g_mu;
+
+int default_device()
+{
+	const char *lr = getenv("LOCAL_RANK");
+	return lr ? atoi(lr) : 0;
+}
+
+int ensure_ctx(int device = -1)
+{
+	if (g_ctx.ready && g_ctx.pid != getpid()) {
+		// forked child: the parent's HIP state is unusable here; start clean (nothing is freed)
+		g_ctx = Context();
+	}
+	if (g_ctx.ready) {
+		if (device >= 0 && device != g_ctx.device)
+			return fail(CCT_E_ARG, "library already bound to device %d", g_ctx.device);
+		HIP_TRY(hipSetDevice(g_ctx.device));
+		return CCT_OK;
+	}
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return fail(CCT_E_DEVICE, "no HIP device available (%s); libcompact_hip has no CPU fallback",
+		            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	const int dev = device >= 0 ? device : default_device();
+	if (dev >= count) return fail(CCT_E_DEVICE, "device %d requested but only %d visible", dev, count);
+	HIP_TRY(hipSetDevice(dev));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, dev));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(CCT_E_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
+	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+	g_ctx.h_stage.pinned_host = true;
+	g_ctx.device = dev;
+	g_ctx.pid = getpid();
+	if (g_ctx.zlib_threads <= 0) {
+		unsigned hc = std::thread::hardware_concurrency();
+		g_ctx.zlib_threads = hc ? (int)hc : 1;
+	}
+	g_ctx.ready = true;
+	return CCT_OK;
+}
+
+int get_lut(int width, int height, const int32_t **out)
+{
+	auto key = std::make_pair(width, height);
+	auto it = g_ctx.luts.find(key);
+	if (it != g_ctx.luts.end()) { *out = it->second; return CCT_OK; }
+	const size_t N = (size_t)width * height;
+	std::vector<int32_t> host(N ? N : 1);
+	if (!gilbert_table(width, height, host.data())) return fail(CCT_E_SHAPE, "traversal generation failed for %dx%d", width, height);
+	int32_t *d = nullptr;
+	HIP_TRY(hipMalloc(&d, (N ? N : 1) * sizeof(int32_t)));
+	HIP_TRY(hipMemcpy(d, host.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+	g_ctx.luts[key] = d;
+	*out = d;
+	return CCT_OK;
+}
+
+bool bs_ok(int bs) { return bs == 4 || bs == 8 || bs == 16 || bs == 32 || bs == 64; }
+
+int check_shape(int n, int width, int height, int bs)
+{
+	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
+	if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+		return fail(CCT_E_ARG, "shape %dx%d outside the 16-bit header fields", width, height);
+	if (!bs_ok(bs)) return fail(CCT_E_ARG, "block_size %d not supported by the HIP path (4, 8, 16, 32, 64)", bs);
+	const int64_t N = (int64_t)width * height;
+	if (N % bs != 0) return fail(CCT_E_SHAPE, "cannot reshape array of size %lld into blocks of %d", (long long)N, bs);
+	if (N >= (int64_t)1 << 30) return fail(CCT_E_ARG, "slices of 2^30 pixels or more are not supported");
+	return CCT_OK;
+}
+
+// run fn(i) for i in [0, n) on a team of host threads
+template <class F>
+void parallel_for(int n, int threads, F fn)
+{
+	if (n <= 0) return;
+	const int nt = std::max(1, std::min(threads, n));
+	if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+	std::atomic<int> next(0);
+	std::vector<std::thread> team;
+	team.reserve(nt);
+	for (int t = 0; t < nt; t++)
+		team.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+	for (auto &th : team) th.join();
+}
+
+int encode_payload_locked(const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
+                          int eof, uint8_t *d_payload, size_t stride, uint32_t *d_sizes, uint32_t *d_status,
+                          cct_slice_stats *d_stats, uint8_t *d_roles)
+{
+	const int N = width * height, NB = N / bs;
+	if (stride < cct_payload_stride(width, height, bs)) return fail(CCT_E_CAP, "payload stride %zu too small", stride);
+	if (n == 0) return CCT_OK;
+	EncArgs a{};
+	a.images = d_images;
+	a.lut = nullptr;
+	if (flags & CCT_FLAG_FRACTAL) { int rc = get_lut(width, height, &a.lut); if (rc) return rc; }
+	a.N = N; a.NB = NB; a.eof = eof; a.flags = flags;
+	a.payload = d_payload; a.stride = stride; a.sizes = d_sizes; a.status = d_status;
+	a.stats = reinterpret_cast<uint32_t *>(d_stats); a.roles_out = d_roles;
+	bool role_in_lds = true;
+	(void)enc_lds_bytes(NB, &role_in_lds);
+	const size_t per = (size_t)n * NB;
+	int rc;
+	if (!role_in_lds) { if ((rc = g_ctx.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)g_ctx.e_role.p; }
+	if ((rc = g_ctx.e_lidx.ensure(per * 4))) return rc;
+	if ((rc = g_ctx.e_lmask.ensure(per * 8))) return rc;
+	if ((rc = g_ctx.e_lcur.ensure(per))) return rc;
+	a.ws_lidx = (uint32_t *)g_ctx.e_lidx.p; a.ws_lmask = (uint64_t *)g_ctx.e_lmask.p; a.ws_lcur = (uint8_t *)g_ctx.e_lcur.p;
+	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
+	return CCT_OK;
+}
+
+int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_t *d_sizes, int n, int width,
+                          int height, int bs, int fractal, uint16_t *d_images, uint32_t *d_status)
+{
+	const int N = width * height, NB = N / bs;
+	if (stride % 16 != 0) return fail(CCT_E_ARG, "payload stride must be a multiple of 16");
+	if (n == 0) return CCT_OK;
+	DecArgs a{};
+	a.payload = d_payload; a.stride = stride; a.sizes = d_sizes;
+	a.lut = nullptr;
+	if (fractal) { int rc = get_lut(width, height, &a.lut); if (rc) return rc; }
+	a.N = N; a.NB = NB; a.images = d_images; a.status = d_status;
+	const size_t per = (size_t)n * NB, jper = (size_t)n * ((size_t)NB / 2 + 1);
+	int rc;
+	if ((rc = g_ctx.d_role.ensure(per))) return rc;
+	if ((rc = g_ctx.d_slot.ensure(per * 4))) return rc;
+	if ((rc = g_ctx.d_jord.ensure(jper * 4))) return rc;
+	if ((rc = g_ctx.d_jval.ensure(jper))) return rc;
+	a.ws_role = (uint8_t *)g_ctx.d_role.p; a.ws_slot = (uint32_t *)g_ctx.d_slot.p;
+	a.ws_jord = (uint32_t *)g_ctx.d_jord.p; a.ws_jval = (uint8_t *)g_ctx.d_jval.p;
+	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
+	return CCT_OK;
+}
+
+}  // namespace
+}  // namespace cct
+
+using namespace cct;
+
+extern "C" {
+
+int cct_version(void) { return CCT_ABI_VERSION; }
+const char *cct_last_error(void) { return g_err; }
+
+int cct_init(int device)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	return ensure_ctx(device);
+}
+
+int cct_shutdown(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!g_ctx.ready || g_ctx.pid != getpid()) { g_ctx = Context(); return CCT_OK; }
+	(void)hipSetDevice(g_ctx.device);
+	(void)hipStreamSynchronize(g_ctx.stream);
+	for (auto &kv : g_ctx.luts) (void)hipFree(kv.second);
+	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
+	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
+	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage};
+	for (DevBuf *b : bufs) b->release();
+	(void)hipStreamDestroy(g_ctx.stream);
+	g_ctx = Context();
+	return CCT_OK;
+}
+
+int cct_device_info(char *name, size_t name_cap, int *compute_units, uint64_t *hbm_bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, g_ctx.device));
+	if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+	if (compute_units) *compute_units = prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+	return CCT_OK;
+}
+
+int cct_dev_alloc(void **d_ptr, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+	return CCT_OK;
+}
+int cct_dev_free(void *d_ptr)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipFree(d_ptr));
+	return CCT_OK;
+}
+int cct_h2d(void *d_dst, const void *h_src, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	return CCT_OK;
+}
+int cct_d2h(void *h_dst, const void *d_src, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	return CCT_OK;
+}
+int cct_dev_memset(void *d_dst, int value, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(d_dst, value, bytes, g_ctx.stream));
+	return CCT_OK;
+}
+int cct_sync(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	return CCT_OK;
+}
+
+int cct_event_create(void **ev)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	hipEvent_t e;
+	HIP_TRY(hipEventCreate(&e));
+	*ev = (void *)e;
+	return CCT_OK;
+}
+int cct_event_record(void *ev)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipEventRecord((hipEvent_t)ev, g_ctx.stream));
+	return CCT_OK;
+}
+int cct_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop));
+	HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+	return CCT_OK;
+}
+int cct_event_destroy(void *ev)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+	return CCT_OK;
+}
+
+int cct_curve_table(int width, int height, int32_t *h_out)
+{
+	if (width <= 0 || height <= 0 || !h_out) return fail(CCT_E_ARG, "bad curve arguments");
+	return gilbert_table(width, height, h_out) ? CCT_OK : fail(CCT_E_SHAPE, "traversal generation failed");
+}
+
+size_t cct_payload_stride(int width, int height, int block_size)
+{
+	if (width <= 0 || height <= 0 || block_size <= 0) return 0;
+	const size_t N = (size_t)width * height, NB = N / block_size;
+	// every pixel a 2-byte token, one jump byte per pair of blocks, EOF, flush padding
+	const size_t need = 2 * N + NB / 2 + 1 + 16;
+	return (need + 255) & ~(size_t)255;
+}
+
+size_t cct_file_bound(int width, int height, int block_size)
+{
+	const size_t p = cct_payload_stride(width, height, block_size);
+	return ((13 + compressBound((uLong)p) + 63) & ~(size_t)63);
+}
+
+int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int height, int block_size, uint32_t flags,
+                           int eof_byte, uint8_t *d_payload, size_t payload_stride, uint32_t *d_payload_sizes,
+                           uint32_t *d_status, cct_slice_stats *d_stats, uint8_t *d_roles)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = check_shape(n, width, height, block_size);
+	if (rc) return rc;
+	if ((rc = ensure_ctx())) return rc;
+	return encode_payload_locked(d_images, n, width, height, block_size, flags, eof_byte, d_payload, payload_stride,
+	                             d_payload_sizes, d_status, d_stats, d_roles);
+}
+
+int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
+                     uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
+                     uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status,
+                     uint32_t *h_payload_sizes, cct_slice_stats *h_stats)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = check_shape(n, width, height, block_size);
+	if (rc) return rc;
+	if ((rc = ensure_ctx())) return rc;
+	if (n == 0) return CCT_OK;
+	const size_t N = (size_t)width * height;
+	const size_t stride = cct_payload_stride(width, height, block_size);
+	const bool defl = (flags & CCT_FLAG_DEFLATE) != 0;
+	if (out_stride < (defl ? cct_file_bound(width, height, block_size) : 13 + stride))
+		return fail(CCT_E_CAP, "out_stride %zu too small", out_stride);
+
+	const uint16_t *d_img = images;
+	if (!images_on_device) {
+		if ((rc = g_ctx.e_images.ensure((size_t)n * N * 2))) return rc;
+		HIP_TRY(hipMemcpyAsync(g_ctx.e_images.p, images, (size_t)n * N * 2, hipMemcpyHostToDevice, g_ctx.stream));
+		d_img = (const uint16_t *)g_ctx.e_images.p;
+	}
+	if ((rc = g_ctx.e_payload.ensure((size_t)n * stride))) return rc;
+	if ((rc = g_ctx.e_sizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = g_ctx.e_status.ensure((size_t)n * 4))) return rc;
+	if ((rc = g_ctx.h_stage.ensure((size_t)n * stride))) return rc;
+	if ((rc = g_ctx.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
+	rc = encode_payload_locked(d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)g_ctx.e_payload.p, stride,
+	                           (uint32_t *)g_ctx.e_sizes.p, (uint32_t *)g_ctx.e_status.p,
+	                           h_stats ? (cct_slice_stats *)g_ctx.e_stats.p : nullptr, nullptr);
+	if (rc) return rc;
+	if (h_stats)
+		HIP_TRY(hipMemcpyAsync(h_stats, g_ctx.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, g_ctx.stream));
+	std::vector<uint32_t> psz(n);
+	HIP_TRY(hipMemcpyAsync(psz.data(), g_ctx.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+	HIP_TRY(hipMemcpyAsync(h_status, g_ctx.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	// bring back only the bytes each slice produced
+	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
+	for (int i = 0; i < n; i++) {
+		if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
+		HIP_TRY(hipMemcpyAsync(stage + (size_t)i * stride, (uint8_t *)g_ctx.e_payload.p + (size_t)i * stride, psz[i],
+		                       hipMemcpyDeviceToHost, g_ctx.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+
+	std::atomic<int> zerr(0);
+	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
+		uint8_t *o = h_out + (size_t)i * out_stride;
+		// 13-byte header, core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
+		o[0] = (uint8_t)magic[0]; o[1] = (uint8_t)magic[1]; o[2] = (uint8_t)magic[2]; o[3] = (uint8_t)magic[3];
+		o[4] = (uint8_t)((width >> 8) & 0xFF); o[5] = (uint8_t)(width & 0xFF);
+		o[6] = (uint8_t)((height >> 8) & 0xFF); o[7] = (uint8_t)(height & 0xFF);
+		o[8] = (uint8_t)(channels & 0xFF); o[9] = (uint8_t)(bytes_per_channel & 0xFF);
+		o[10] = (flags & CCT_FLAG_FRACTAL) ? 1 : 0;
+		o[11] = (flags & CCT_FLAG_SEGMENTATION) ? 1 : 0;
+		o[12] = defl ? 1 : 0;
+		const uint8_t *pl = stage + (size_t)i * stride;
+		if (defl) {  // zlib.compress(data, level=9), core.py:340
+			uLongf dl = (uLongf)(out_stride - 13);
+			const int zr = compress2(o + 13, &dl, pl, psz[i], 9);
+			if (zr != Z_OK) { zerr.store(zr); h_out_sizes[i] = 0; return; }
+			h_out_sizes[i] = 13 + (uint32_t)dl;
+		} else {
+			memcpy(o + 13, pl, psz[i]);
+			h_out_sizes[i] = 13 + psz[i];
+		}
+	});
+	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
+	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
+	return CCT_OK;
+}
+
+int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_header *out)
+{
+	if (!h_file || !out) return fail(CCT_E_ARG, "null argument");
+	if (len < 13) return fail(CCT_E_STREAM, "file shorter than the 13-byte header");
+	if (memcmp(h_file, magic, 4) != 0) return fail(CCT_E_MAGIC, "Image does not contain valid header");
+	out->width = (h_file[4] << 8) | h_file[5];
+	out->height = (h_file[6] << 8) | h_file[7];
+	out->channels = h_file[8];
+	out->bytes_per_channel = h_file[9];
+	out->fractal = h_file[10] != 0;
+	out->segmentation = h_file[11] != 0;
+	out->deflate = h_file[12] != 0;
+	return CCT_OK;
+}
+
+int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, const uint32_t *d_payload_sizes, int n,
+                           int width, int height, int block_size, int fractal, uint16_t *d_images, uint32_t *d_status)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = check_shape(n, width, height, block_size);
+	if (rc) return rc;
+	if ((rc = ensure_ctx())) return rc;
+	return decode_payload_locked(d_payload, payload_stride, d_payload_sizes, n, width, height, block_size, fractal,
+	                             d_images, d_status);
+}
+
+int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, int block_size, const char magic[4],
+                     uint16_t *images, int images_on_device, size_t images_cap_px, uint32_t *h_status)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
+	if (n == 0) return CCT_OK;
+	cct_header h0;
+	int rc = cct_read_header(h_files + h_offsets[0], (size_t)(h_offsets[1] - h_offsets[0]), magic, &h0);
+	if (rc) return rc;
+	for (int i = 1; i < n; i++) {
+		cct_header h;
+		if ((rc = cct_read_header(h_files + h_offsets[i], (size_t)(h_offsets[i + 1] - h_offsets[i]), magic, &h))) return rc;
+		if (h.width != h0.width || h.height != h0.height || h.fractal != h0.fractal || h.deflate != h0.deflate)
+			return fail(CCT_E_MIXED, "file %d differs from file 0 in shape or flags", i);
+	}
+	if (h0.width == 0 || h0.height == 0) return fail(CCT_E_SHAPE, "empty image");
+	if ((rc = check_shape(n, h0.width, h0.height, block_size))) return rc;
+	if ((rc = ensure_ctx())) return rc;
+	const size_t N = (size_t)h0.width * h0.height;
+	if (images_cap_px < (size_t)n * N) return fail(CCT_E_CAP, "output holds %zu pixels, need %zu", images_cap_px, (size_t)n * N);
+	const size_t stride = cct_payload_stride(h0.width, h0.height, block_size);
+	if ((rc = g_ctx.h_stage.ensure((size_t)n * stride))) return rc;
+	if ((rc = g_ctx.d_payload.ensure((size_t)n * stride))) return rc;
+	if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = g_ctx.d_status.ensure((size_t)n * 4))) return rc;
+	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
+	std::vector<uint32_t> psz(n);
+	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
+	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421
+	parallel_for(n, h0.deflate ? g_ctx.zlib_threads : 1, [&](int i) {
+		const uint8_t *body = h_files + h_offsets[i] + 13;
+		const size_t blen = (size_t)(h_offsets[i + 1] - h_offsets[i]) - 13;
+		uint8_t *dst = stage + (size_t)i * stride;
+		if (h0.deflate) {
+			uLongf dl = (uLongf)stride;
+			const int zr = uncompress(dst, &dl, body, (uLong)blen);
+			if (zr == Z_BUF_ERROR) { h_status[i] = CCT_E_STREAM; psz[i] = 0; }  // longer than any valid stream
+			else if (zr != Z_OK) { h_status[i] = CCT_E_ZLIB; psz[i] = 0; }
+			else psz[i] = (uint32_t)dl;
+		} else {
+			if (blen > stride) { h_status[i] = CCT_E_STREAM; psz[i] = 0; }
+			else { memcpy(dst, body, blen); psz[i] = (uint32_t)blen; }
+		}
+	});
+	for (int i = 0; i < n; i++)
+		HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.d_payload.p + (size_t)i * stride, stage + (size_t)i * stride,
+		                       (psz[i] + 15u) & ~15u, hipMemcpyHostToDevice, g_ctx.stream));
+	HIP_TRY(hipMemcpyAsync(g_ctx.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, g_ctx.stream));
+	uint16_t *d_img = images;
+	if (!images_on_device) {
+		if ((rc = g_ctx.d_images.ensure((size_t)n * N * 2))) return rc;
+		d_img = (uint16_t *)g_ctx.d_images.p;
+	}
+	rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
+	                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p);
+	if (rc) return rc;
+	std::vector<uint32_t> dst(n);
+	HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+	if (!images_on_device)
+		HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	int first = CCT_OK;
+	for (int i = 0; i < n; i++) {
+		if (h_status[i] == CCT_OK) {
+			if (dst[i] & CCT_ST_STREAM) h_status[i] = CCT_E_STREAM;
+			else if (dst[i] & CCT_ST_OVERFLOW) h_status[i] = CCT_E_OVERFLOW;
+		}
+		if (h_status[i] != CCT_OK && first == CCT_OK) {
+			first = (int)h_status[i];
+			fail(first, "file %d: %s", i,
+			     first == CCT_E_ZLIB ? "invalid DEFLATE stream"
+			     : first == CCT_E_OVERFLOW ? "int too big to convert (pixel left the 16-bit range)"
+			                               : "truncated or malformed token stream");
+		}
+	}
+	return first;
+}
+
+int cct_set_option(const char *key, int value)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
+	if (!strcmp(key, "wg_threads")) {
+		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
+		g_ctx.wg_threads = value; return CCT_OK;
+	}
+	return fail(CCT_E_ARG, "unknown option %s", key);
+}
+int cct_get_option(const char *key, int *value)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
+	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
+	return fail(CCT_E_ARG, "unknown option %s", key);
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal declarations shared by the host side (api.cpp) and the HIP kernels.
+// Not part of the C ABI (see include/compact_hip.h).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+namespace cct {
+
+// ---- encode kernel geometry ----------------------------------------------------------
+constexpr int ENC_CH = 8192;          // pixels per chunk staged in LDS (multiple of every block size)
+constexpr int ENC_RING = 4;           // chunks resident in the LDS ring (power of two)
+constexpr int ENC_LIST_CAP = 1536;    // difficult-block records kept in LDS; the rest spill to HBM
+constexpr int ENC_STG_BYTES = 2 * ENC_CH + ENC_CH / 8 + 64;  // token staging for one chunk + carry
+constexpr int ENC_MAX_LDS_ROLE = 48 * 1024;  // role[] lives in LDS when NB <= this
+
+constexpr uint8_t ROLE_PARTNER = 0xFF; // block consumed as the second half of a meshed pair
+
+struct EncArgs {
+	const uint16_t *images;   // n * N pixels
+	const int32_t *lut;       // traversal order O[N] (device) or nullptr for the identity
+	int N, NB;
+	int eof;                  // -1: none
+	uint32_t flags;           // CCT_FLAG_*
+	uint8_t *payload; size_t stride;
+	uint32_t *sizes; uint32_t *status;
+	uint8_t *ws_role;         // n * NB bytes when role[] does not fit LDS, else nullptr
+	uint32_t *ws_lidx;        // n * NB spill: difficult-block index
+	uint64_t *ws_lmask;       // n * NB spill: candidate masks
+	uint8_t *ws_lcur;         // n * NB spill: cur counts
+	uint32_t *stats;          // optional n * 4: short, full, jump tokens, difficult blocks
+	uint8_t *roles_out;       // optional n * NB: final role of every block (BLOCK_JUMPS)
+};
+
+size_t enc_lds_bytes(int NB, bool *role_in_lds);
+hipError_t launch_encode(const EncArgs &a, int n, int block_size, int threads, hipStream_t s);
+
+// ---- decode kernel geometry ----------------------------------------------------------
+constexpr int DEC_SEG = 16;           // payload bytes parsed per lane per step
+constexpr int DEC_JLIST_CAP = 2048;   // jump records kept in LDS; the rest spill to HBM
+
+struct DecArgs {
+	const uint8_t *payload; size_t stride; const uint32_t *sizes;
+	const int32_t *lut;       // traversal order or nullptr
+	int N, NB;
+	uint16_t *images; uint32_t *status;
+	uint8_t *ws_role;         // n * NB bytes (always in HBM for decode)
+	uint32_t *ws_slot;        // n * NB: stream slot -> leader block | kind << 30
+	uint32_t *ws_jord;        // n * (NB/2+1) spill: jump ordinals
+	uint8_t *ws_jval;         // n * (NB/2+1) spill: jump distances
+};
+
+hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s);
+
+}  // namespace cct

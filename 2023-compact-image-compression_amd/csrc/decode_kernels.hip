@@ -1,0 +1,351 @@
+// CompaCT decode, token stream -> raster (core.py:423-520), one workgroup per slice.
+//
+// The token stream is a 2-state automaton over bytes ("token start" / "second byte of a full
+// token"), so token boundaries come from a scan of 2->2 state maps: every lane parses a 16-byte
+// segment under BOTH entry hypotheses, a wave/workgroup scan composes the maps, and the lane
+// then knows its true entry state, how many pixels precede it and the running pixel value
+// (pixel values are a prefix sum of the signed deltas, core.py:503-505, 514-515).
+//
+//   pass A  parse the payload, collect the mesh-jump tokens (core.py:484-494) with their pixel
+//           ordinals;
+//   resolve one lane replays the ~100-700 jumps in stream order against a 64-bit window of
+//           already-claimed partner blocks -> role[b] (0 single, 1..63 pair leader, 0xFF partner);
+//           a workgroup scan over role[] then gives every 16-pixel stream slot its block;
+//   pass B  parse again, now scattering each pixel to raster position O[block*bs + t].
+//
+// Streams a reference encoder cannot produce (reserved tag bytes, a jump that is not at a
+// block boundary, a jump onto a claimed block, truncation) set CCT_ST_STREAM instead of
+// replaying the reference's accidental behaviour on them; see DESIGN.md.
+#include "cct_internal.h"
+#include "../../include/compact_hip.h"
+
+namespace cct {
+namespace {
+
+struct SegStats {
+	uint32_t exit_state;  // 1: segment ends inside a full token
+	uint32_t npix;        // pixel tokens that START in the segment
+	uint32_t njump;       // jump tokens in the segment
+	int32_t sdelta;       // sum of their deltas
+};
+
+__device__ __forceinline__ int tok_delta_full(uint32_t b0, uint32_t b1)
+{
+	int x = (int)(((b0 << 8) | b1) & 0xFFFu);
+	return x > 2048 ? x - 4096 : x;  // signed(x, 12): `x > max/2`, core.py:56-60
+}
+__device__ __forceinline__ int tok_delta_short(uint32_t b0)
+{
+	int x = (int)(b0 & 0x7Fu);
+	return x > 64 ? x - 128 : x;  // signed(x, 7)
+}
+
+// bytes of the segment come as 4 little-endian words + the first byte of the next segment
+__device__ __forceinline__ uint32_t seg_byte(const uint4 &w, uint32_t nxt, int i)
+{
+	const uint32_t word = (i < 4) ? w.x : (i < 8) ? w.y : (i < 12) ? w.z : (i < 16) ? w.w : nxt;
+	return (word >> ((i & 3) * 8)) & 0xFFu;
+}
+
+__device__ __forceinline__ SegStats seg_walk(const uint4 &w, uint32_t nxt, int nvalid, int entry)
+{
+	SegStats st{0, 0, 0, 0};
+	int i = entry;
+	while (i < nvalid) {
+		const uint32_t c = seg_byte(w, nxt, i);
+		if ((c & 0xF0u) == 0xE0u) {
+			st.sdelta += tok_delta_full(c, seg_byte(w, nxt, i + 1));
+			st.npix++;
+			i += 2;
+		} else {
+			if ((c & 0xC0u) == 0x80u) st.njump++;
+			else { st.npix++; if (c < 0x80u) st.sdelta += tok_delta_short(c); }
+			i += 1;
+		}
+	}
+	st.exit_state = (i > nvalid) ? 1u : 0u;
+	if (nvalid <= 0) st.exit_state = (uint32_t)entry;
+	return st;
+}
+
+// state maps over {0,1} packed as f(0) | f(1) << 1
+__device__ __forceinline__ uint32_t map_apply(uint32_t m, uint32_t s) { return (m >> s) & 1u; }
+__device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier)
+{
+	return map_apply(later, map_apply(earlier, 0)) | (map_apply(later, map_apply(earlier, 1)) << 1);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t t = __shfl_up(v, d);
+		if (lane >= d) v += t;
+	}
+	return v;
+}
+
+struct Parse {  // what one lane knows about its segment after the workgroup scans
+	uint32_t entry;      // true entry state
+	uint32_t pix_base;   // pixel ordinal of its first pixel token (within the whole stream)
+	int32_t val_base;    // pixel value before its first token
+	uint32_t jump_base;  // index of its first jump in the slice's jump list
+	SegStats st;
+};
+
+// One parsing step over T*16 payload bytes starting at `base`.  Updates the carried stream
+// state (st_in, npix, val, njump) and returns the lane's view.  Contains barriers.
+__device__ __forceinline__ Parse parse_step(const uint4 &w, uint32_t nxt, int nvalid,
+                                           uint32_t *scratch, uint32_t &st_carry,
+                                           uint32_t &npix_carry, int32_t &val_carry,
+                                           uint32_t &njump_carry)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	const SegStats s0 = seg_walk(w, nxt, nvalid, 0);
+	const SegStats s1 = seg_walk(w, nxt, nvalid, 1);
+	// inclusive scan of state maps inside the wave
+	uint32_t m = s0.exit_state | (s1.exit_state << 1);
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(m, d);
+		if (lane >= d) m = map_compose(m, t);
+	}
+	uint32_t excl = __shfl_up(m, 1);
+	if (lane == 0) excl = 2u;  // identity map
+	if (lane == 63) scratch[wave] = m;
+	__syncthreads();
+	uint32_t st_wave = st_carry, st_end = st_carry;
+	for (int x = 0; x < nw; x++) {
+		const uint32_t wm = scratch[x];
+		if (x < wave) st_wave = map_apply(wm, st_wave);
+		st_end = map_apply(wm, st_end);
+	}
+	__syncthreads();
+	Parse p;
+	p.entry = map_apply(excl, st_wave);
+	p.st = p.entry ? s1 : s0;
+	// scans of pixel count, delta sum and jump count
+	const uint32_t ip = wave_incl_scan_u32(p.st.npix);
+	const uint32_t iv = wave_incl_scan_u32((uint32_t)p.st.sdelta);
+	const uint32_t ij = wave_incl_scan_u32(p.st.njump);
+	if (lane == 63) { scratch[wave] = ip; scratch[16 + wave] = iv; scratch[32 + wave] = ij; }
+	__syncthreads();
+	uint32_t bp = 0, bv = 0, bj = 0, tp = 0, tv = 0, tj = 0;
+	for (int x = 0; x < nw; x++) {
+		const uint32_t xp = scratch[x], xv = scratch[16 + x], xj = scratch[32 + x];
+		if (x < wave) { bp += xp; bv += xv; bj += xj; }
+		tp += xp; tv += xv; tj += xj;
+	}
+	__syncthreads();
+	p.pix_base = npix_carry + bp + ip - p.st.npix;
+	p.val_base = val_carry + (int32_t)(bv + iv - (uint32_t)p.st.sdelta);
+	p.jump_base = njump_carry + bj + ij - p.st.njump;
+	st_carry = st_end;
+	npix_carry += tp;
+	val_carry += (int32_t)tv;
+	njump_carry += tj;
+	return p;
+}
+
+template <int BS>
+__global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
+{
+	__shared__ uint32_t scratch[64];
+	__shared__ uint32_t l_jord[DEC_JLIST_CAP];
+	__shared__ uint8_t l_jval[DEC_JLIST_CAP];
+	__shared__ uint32_t s_status;
+
+	const int tid = threadIdx.x, T = blockDim.x;
+	const int s = blockIdx.x;
+	const int N = a.N, NB = a.NB;
+	const uint8_t *P = a.payload + (size_t)s * a.stride;
+	const uint32_t L = a.sizes[s];
+	// ByteReader.padding_len = 1 (core.py:136-142): the last byte is never returned by read()
+	const uint32_t Lr = min((uint32_t)a.stride, L) > 0 ? min((uint32_t)a.stride, L) - 1u : 0u;
+	const int32_t *lut = a.lut;
+	uint16_t *out = a.images + (size_t)s * N;
+	uint8_t *role = a.ws_role + (size_t)s * NB;
+	uint32_t *slot_tab = a.ws_slot + (size_t)s * NB;
+	const size_t jcap = (size_t)NB / 2 + 1;
+	uint32_t *g_jord = a.ws_jord + (size_t)s * jcap;
+	uint8_t *g_jval = a.ws_jval + (size_t)s * jcap;
+
+	if (tid == 0) s_status = 0;
+	for (int b = tid; b < NB; b += T) role[b] = 0;
+	__syncthreads();
+
+	auto load_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt, int &nvalid) {
+		w = make_uint4(0, 0, 0, 0);
+		nxt = 0;
+		nvalid = 0;
+		if (seg_start < Lr) {
+			w = *reinterpret_cast<const uint4 *>(P + seg_start);  // stride is a multiple of 256
+			nvalid = (int)min(16u, Lr - seg_start);
+			if (seg_start + 16u < Lr) nxt = P[seg_start + 16u];
+		}
+	};
+	auto jset = [&](uint32_t k, uint32_t ord, uint32_t j) {
+		if (k < DEC_JLIST_CAP) { l_jord[k] = ord; l_jval[k] = (uint8_t)j; }
+		else if (k - DEC_JLIST_CAP < jcap) { g_jord[k - DEC_JLIST_CAP] = ord; g_jval[k - DEC_JLIST_CAP] = (uint8_t)j; }
+	};
+
+	// ------------------------------------------------------------------ pass A: jump tokens
+	uint32_t st_c = 0, npix_c = 0, nj_c = 0;
+	int32_t val_c = 0;
+	for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG) {
+		uint4 w; uint32_t nxt; int nvalid;
+		load_seg(base + (uint32_t)tid * DEC_SEG, w, nxt, nvalid);
+		const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
+		if (p.st.njump) {
+			int i = (int)p.entry;
+			uint32_t ord = p.pix_base, k = p.jump_base;
+			while (i < nvalid) {
+				const uint32_t c = seg_byte(w, nxt, i);
+				if ((c & 0xF0u) == 0xE0u) { ord++; i += 2; }
+				else {
+					if ((c & 0xC0u) == 0x80u) { if (ord < (uint32_t)N) jset(k, ord, c & 0x3Fu); k++; }
+					else ord++;
+					i += 1;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (npix_c < (uint32_t)N && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);  // ran out of tokens
+
+	// ------------------------------------------------------------------ resolve jumps -> role[]
+	if (tid == 0) {
+		const uint32_t nj = nj_c;
+		uint32_t F = 0;          // frontier: next block in traversal order not yet emitted as a leader
+		uint64_t win = 0;        // bit t: block F+t already claimed as a partner
+		uint32_t slots_done = 0; // 16-pixel stream slots consumed before the frontier
+		bool bad = false;
+		for (uint32_t k = 0; k < nj && !bad; k++) {
+			uint32_t ord, j;
+			if (k < DEC_JLIST_CAP) { ord = l_jord[k]; j = l_jval[k]; }
+			else if (k - DEC_JLIST_CAP < jcap) { ord = g_jord[k - DEC_JLIST_CAP]; j = g_jval[k - DEC_JLIST_CAP]; }
+			else { bad = true; break; }
+			if (ord >= (uint32_t)N) break;  // tokens past the last pixel are never read
+			if (ord % BS != 0) { bad = true; break; }
+			const uint32_t sslot = ord / BS;
+			if (sslot < slots_done) { bad = true; break; }
+			uint32_t remaining = sslot - slots_done;  // single blocks between the two pairs
+			while (remaining) {
+				if (win == 0) { F += remaining; remaining = 0; break; }
+				const uint32_t o = (uint32_t)__ffsll((long long)win) - 1u;  // singles before next partner
+				if (o >= remaining) { F += remaining; win >>= remaining; remaining = 0; }
+				else { F += o + 1; win = (o + 1 >= 64u) ? 0ull : (win >> (o + 1)); remaining -= o; }
+			}
+			while (win & 1ull) { F++; win >>= 1; }
+			const uint32_t Lb = F, pb = F + j;
+			if (j == 0 || pb >= (uint32_t)NB || ((win >> j) & 1ull)) { bad = true; break; }
+			role[Lb] = (uint8_t)j;
+			role[pb] = ROLE_PARTNER;
+			win |= 1ull << j;
+			F = Lb + 1;
+			win >>= 1;
+			slots_done = sslot + 2;
+		}
+		if (bad) atomicOr(&s_status, CCT_ST_STREAM);
+	}
+	__syncthreads();
+
+	// ------------------------------------------------------------------ slot table
+	{
+		uint32_t slot_c = 0;
+		for (int base = 0; base < NB; base += T) {
+			const int b = base + tid;
+			uint32_t r = ROLE_PARTNER, cnt = 0;
+			if (b < NB) { r = role[b]; cnt = (r == ROLE_PARTNER) ? 0u : (r ? 2u : 1u); }
+			const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+			const uint32_t inc = wave_incl_scan_u32(cnt);
+			if (lane == 63) scratch[wave] = inc;
+			__syncthreads();
+			uint32_t bs_ = 0, tot = 0;
+			for (int x = 0; x < nw; x++) { const uint32_t v = scratch[x]; if (x < wave) bs_ += v; tot += v; }
+			__syncthreads();
+			const uint32_t sl = slot_c + bs_ + inc - cnt;
+			if (cnt >= 1 && sl < (uint32_t)NB) slot_tab[sl] = (uint32_t)b | (cnt == 2 ? (1u << 30) : 0u);
+			if (cnt == 2 && sl + 1 < (uint32_t)NB) slot_tab[sl + 1] = (uint32_t)b | (2u << 30);
+			slot_c += tot;
+		}
+		if (slot_c != (uint32_t)NB && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
+	}
+	__syncthreads();
+
+	// ------------------------------------------------------------------ pass B: pixels
+	if (!(s_status & CCT_ST_STREAM)) {
+		st_c = 0; npix_c = 0; nj_c = 0; val_c = 0;
+		for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG) {
+			const uint32_t seg_start = base + (uint32_t)tid * DEC_SEG;
+			uint4 w; uint32_t nxt; int nvalid;
+			load_seg(seg_start, w, nxt, nvalid);
+			const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
+			int i = (int)p.entry;
+			uint32_t ord = p.pix_base;
+			int32_t val = p.val_base;
+			uint32_t flags = 0;
+			bool after_jump = false;
+			while (i < nvalid && ord < (uint32_t)N) {
+				const uint32_t c = seg_byte(w, nxt, i);
+				bool is_pixel = true;
+				if ((c & 0xF0u) == 0xE0u) {
+					if (seg_start + (uint32_t)i + 1u >= Lr) flags |= CCT_ST_STREAM;  // second byte missing
+					val += tok_delta_full(c, seg_byte(w, nxt, i + 1));
+					i += 2;
+				} else if (c < 0x80u) {
+					val += tok_delta_short(c);
+					i += 1;
+				} else if ((c & 0xC0u) == 0x80u) {
+					if (after_jump) flags |= CCT_ST_STREAM;  // two jump bytes in a row
+					is_pixel = false;
+					after_jump = true;
+					i += 1;
+				} else {
+					flags |= CCT_ST_STREAM;  // reserved tags 110xxxxx / 1111xxxx are never emitted
+					i += 1;
+				}
+				if (is_pixel) {
+					after_jump = false;
+					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
+					const uint32_t sl = ord / BS, t = ord % BS;
+					const uint32_t ent = slot_tab[sl];
+					const uint32_t b = ent & 0x3FFFFFFFu, kind = ent >> 30;
+					uint32_t pos;
+					if (kind == 0) pos = b * BS + t;
+					else {
+						const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
+						const uint32_t blk = (mm & 1u) ? b + role[b] : b;
+						pos = blk * BS + (mm >> 1);
+					}
+					out[lut ? lut[pos] : (int)pos] = (uint16_t)val;
+					ord++;
+				}
+			}
+			if (flags) atomicOr(&s_status, flags);
+		}
+		if (npix_c < (uint32_t)N && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
+	}
+	__syncthreads();
+	if (tid == 0) a.status[s] = s_status;
+}
+
+}  // namespace
+
+hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s)
+{
+	void (*k)(DecArgs) = nullptr;
+	switch (block_size) {
+	case 4: k = decode_kernel<4>; break;
+	case 8: k = decode_kernel<8>; break;
+	case 16: k = decode_kernel<16>; break;
+	case 32: k = decode_kernel<32>; break;
+	case 64: k = decode_kernel<64>; break;
+	default: return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k, dim3(n), dim3(threads), 0, s, a);
+	return hipGetLastError();
+}
+
+}  // namespace cct

@@ -1,0 +1,158 @@
+/*
+ * compact_hip.h -- C ABI of libcompact_hip.so, the MI355X (gfx950) implementation of the
+ * CompaCT per-slice encode/decode hot path.
+ *
+ * The reference (taaha-khan/2023-CompaCT-Image-Compression) is pure Python and has no
+ * FFI of its own: its contract is the class surface codec.core.Encoder / Decoder
+ * (src/codec/core.py:170-365, 367-543).  The entry points below are what a ctypes
+ * binding for that surface needs; each one names the reference code it replaces.
+ * The Python mirror that binds them lives in 2023-compact-image-compression_amd/codec/
+ * and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * CCT_E_* code and never throws; buffers are caller-allocated; "d_" pointers are device
+ * (HBM) addresses obtained from cct_dev_alloc (or any hipMalloc), "h_" pointers are host
+ * addresses.  All launches go to one internal HIP stream per process; calls are
+ * serialised by an internal mutex.  The library initialises HIP lazily on first use and
+ * re-initialises after fork (callers such as scripts/evaluate.py:107 fork workers).
+ *
+ * There is NO CPU fallback: every function that computes needs a gfx950 device and fails
+ * with CCT_E_DEVICE when none is usable.
+ */
+#ifndef COMPACT_HIP_H
+#define COMPACT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCT_ABI_VERSION 1
+
+/* error codes */
+#define CCT_OK 0
+#define CCT_E_MAGIC 1     /* header magic mismatch          -> ValueError   (core.py:388-389) */
+#define CCT_E_ZLIB 2      /* DEFLATE stream invalid          -> zlib.error   (core.py:421)     */
+#define CCT_E_OVERFLOW 3  /* pixel left [0,65535] in decode  -> OverflowError(core.py:506,516) */
+#define CCT_E_STREAM 4    /* truncated / malformed token stream (TypeError/IndexError there)  */
+#define CCT_E_SHAPE 5     /* width*height % block_size != 0  -> ValueError   (core.py:245,429) */
+#define CCT_E_CAP 6       /* caller buffer too small */
+#define CCT_E_NOMEM 7
+#define CCT_E_DEVICE 8    /* no usable gfx950 device / HIP runtime error */
+#define CCT_E_ARG 9       /* unsupported argument (block_size not in {4,8,16,32,64}, n<0, ...) */
+#define CCT_E_MIXED 10    /* decode batch whose members differ in shape or flags */
+
+/* encoder flags: config['encoder']['transforms'] + deflate_compression (core.py:207-209) */
+#define CCT_FLAG_FRACTAL 1u       /* transforms.fractal      (core.py:234) */
+#define CCT_FLAG_SEGMENTATION 2u  /* transforms.segmentation (core.py:251) */
+#define CCT_FLAG_DEFLATE 4u       /* deflate_compression     (core.py:337) */
+#define CCT_FLAG_SIGNED_SEG 8u    /* caller's array dtype is int16: segmentation sees signed
+                                     values (core.py:254 image.flatten().tolist()) */
+
+/* per-slice status bits written by the device kernels (0 = clean) */
+#define CCT_ST_Q7 1u         /* encode: a traversal delta outside [-2047,2048] was emitted; the
+                                stream is reference-identical but not decodable (SURVEY App.A Q7) */
+#define CCT_ST_CAP 2u        /* encode: payload stride too small */
+#define CCT_ST_OVERFLOW 4u   /* decode: CCT_E_OVERFLOW condition */
+#define CCT_ST_STREAM 8u     /* decode: CCT_E_STREAM condition */
+
+typedef struct cct_header {  /* the 13-byte .cct header (core.py:193-210 / 385-402) */
+	int32_t width;             /* image.shape[0] */
+	int32_t height;            /* image.shape[1] */
+	int32_t channels;
+	int32_t bytes_per_channel;
+	int32_t fractal, segmentation, deflate;
+} cct_header;
+
+typedef struct cct_slice_stats {  /* Encoder.info / partition statistics of one slice */
+	uint32_t n_short;      /* info['delta'], core.py:317 */
+	uint32_t n_full;       /* info['full'],  core.py:322 */
+	uint32_t n_jump;       /* len(BLOCK_JUMPS), cluster.py:166 */
+	uint32_t n_difficult;  /* len(block_deltas), cluster.py:51-59 */
+} cct_slice_stats;
+
+/* ---- library / device ------------------------------------------------------------- */
+int cct_version(void);                 /* returns CCT_ABI_VERSION */
+const char *cct_last_error(void);      /* thread-local text of the last failure */
+int cct_init(int device);              /* bind HIP device (default: LOCAL_RANK or 0); idempotent */
+int cct_shutdown(void);
+int cct_device_info(char *name, size_t name_cap, int *compute_units, uint64_t *hbm_bytes);
+
+int cct_dev_alloc(void **d_ptr, size_t bytes);
+int cct_dev_free(void *d_ptr);
+int cct_h2d(void *d_dst, const void *h_src, size_t bytes);
+int cct_d2h(void *h_dst, const void *d_src, size_t bytes);
+int cct_dev_memset(void *d_dst, int value, size_t bytes);
+int cct_sync(void);
+/* elapsed-time markers on the library's stream (bench.py: HIP events around the kernels) */
+int cct_event_create(void **ev);
+int cct_event_record(void *ev);
+int cct_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises on ev_stop */
+int cct_event_destroy(void *ev);
+
+/* ---- traversal -------------------------------------------------------------------- */
+/* Replaces GeneralizedHilbertCurve(width, height, get_index=True).generate_all()
+ * (src/codec/curve.py:45-138; call sites core.py:234-237, 423-425).  Host code; shape-only. */
+int cct_curve_table(int width, int height, int32_t *h_out);
+
+/* ---- sizes ------------------------------------------------------------------------ */
+/* bytes one slice's token stream (+EOF) can need; also the stride between slices in d_payload
+ * (a multiple of 256). */
+size_t cct_payload_stride(int width, int height, int block_size);
+/* bytes one .cct file can need (13-byte header + zlib compressBound of the payload) */
+size_t cct_file_bound(int width, int height, int block_size);
+
+/* ---- encode ----------------------------------------------------------------------- */
+/* Stage (i), the HBM-bound part: traversal -> segmentation/mesh -> delta -> tag-byte pack
+ * (+EOF) for n device-resident slices.  Replaces core.py:234-330 + cluster.py:20-199.
+ * d_images: n*width*height uint16 (C order, shape (width,height) each).
+ * d_payload: n * payload_stride bytes; d_payload_sizes[n]; d_status[n] (CCT_ST_* bits). */
+int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int height,
+                           int block_size, uint32_t flags, int eof_byte /* -1 = none */,
+                           uint8_t *d_payload, size_t payload_stride,
+                           uint32_t *d_payload_sizes, uint32_t *d_status,
+                           cct_slice_stats *d_stats /* may be NULL */,
+                           uint8_t *d_roles /* may be NULL; n*NB bytes: the block partition
+                              (cluster.py:49-199) as one role per traversal block: 0 = emitted alone,
+                              1..63 = leader of a meshed pair (BLOCK_JUMPS[b] - b), 0xFF = partner */);
+
+/* Stages (i)+(ii): whole .cct files (header + DEFLATE(level 9) or raw payload) into host
+ * memory.  Replaces Encoder.encode (core.py:212-365) for a batch.  Slice i's file is
+ * h_out[i*out_stride .. +h_out_sizes[i]).  images_on_device selects d_/h_ meaning of `images`. */
+int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int width, int height,
+                     int block_size, uint32_t flags, int eof_byte, const char magic[4],
+                     int channels, int bytes_per_channel,
+                     uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes,
+                     uint32_t *h_status /* CCT_ST_* bits per slice */,
+                     uint32_t *h_payload_sizes /* may be NULL */,
+                     cct_slice_stats *h_stats /* may be NULL */);
+
+/* ---- decode ----------------------------------------------------------------------- */
+/* Replaces Decoder.read_header (core.py:385-402). */
+int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_header *out);
+
+/* Token stream -> raster for n device-resident payloads of one shape.  Replaces
+ * core.py:423-520.  d_payload_sizes[i] counts the trailing EOF byte, which is ignored
+ * exactly like ByteReader.padding_len (core.py:136-142). */
+int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride,
+                           const uint32_t *d_payload_sizes, int n, int width, int height,
+                           int block_size, int fractal,
+                           uint16_t *d_images, uint32_t *d_status);
+
+/* Whole files -> rasters (Decoder.decode with out_path=None, core.py:404-543) for n files of
+ * identical shape/flags laid out back to back: file i = h_files[h_offsets[i] .. h_offsets[i+1]).
+ * Output: n*width*height uint16 at `images` (device or host). */
+int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, int block_size,
+                     const char magic[4], uint16_t *images, int images_on_device,
+                     size_t images_cap_px, uint32_t *h_status /* CCT_E_* code per file */);
+
+/* ---- tuning / introspection (bench.py) --------------------------------------------- */
+int cct_set_option(const char *key, int value);  /* "zlib_threads", "wg_threads", ... */
+int cct_get_option(const char *key, int *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMPACT_HIP_H */

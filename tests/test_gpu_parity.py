@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the reference-generated
+golden fixtures and against the CPU oracle on seeded inputs.  Bit-exact everywhere: the path
+is integer/byte work."""
+import copy
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(gi.GOLDEN, "manifest.json")) as _f:
+    _MAN = json.load(_f)
+CASES = {c["name"]: c for c in _MAN["cases"]}
+
+
+def _config(case):
+    from cct_hip import default_config
+    cfg = default_config()
+    cfg["verbose"] = False
+    o = case["config"]
+    cfg["block_size"] = o.get("block_size", 16)
+    cfg["encoder"]["transforms"]["fractal"] = o.get("fractal", True)
+    cfg["encoder"]["transforms"]["segmentation"] = o.get("segmentation", True)
+    cfg["encoder"]["deflate_compression"] = o.get("deflate", True)
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import cct_hip
+    info = cct_hip.device_info()  # raises if the extension or the GPU is missing: no fallback
+    assert "gfx950" in info["name"]
+    return cct_hip
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_encode_golden(hip, name):
+    from codec.core import Encoder
+    case = CASES[name]
+    img = gi.build_input(case["input"])
+    cfg = _config(case)
+    if "encode_raises" in case:
+        with pytest.raises(ValueError):
+            Encoder(cfg, img).encode()
+        return
+    enc = Encoder(cfg, img)
+    out = enc.encode()
+    assert len(out) == case["len"]
+    assert hashlib.sha1(out).hexdigest() == case["sha1"]
+    if "file" in case:
+        with open(os.path.join(gi.GOLDEN, case["file"]), "rb") as f:
+            assert out == f.read()
+    assert enc.info["delta"] == case["tokens"]["short"]
+    assert enc.info["full"] == case["tokens"]["full"]
+    if "jump" in case["tokens"]:
+        assert enc.block_jumps_count == case["tokens"]["jump"]
+
+
+@pytest.mark.parametrize("name", sorted(n for n, c in CASES.items() if "file" in c))
+def test_decode_golden(hip, name):
+    from codec.core import Decoder
+    case = CASES[name]
+    with open(os.path.join(gi.GOLDEN, case["file"]), "rb") as f:
+        blob = f.read()
+    cfg = _config(case)
+    if "decode_raises" in case:
+        exc = {"OverflowError": OverflowError}[case["decode_raises"]]
+        with pytest.raises(exc):
+            Decoder(cfg, blob).decode()
+        return
+    dec = Decoder(cfg, blob).decode()
+    assert hashlib.sha1(dec).hexdigest() == case["decoded_sha1"]
+    if case["roundtrip"]:
+        assert dec == gi.build_input(case["input"]).tobytes()
+
+
+@pytest.mark.parametrize("name", ["slice0671", "slice3706", "noise64", "q4_block0", "q4_block0_bs4",
+                                  "uniform_160x96", "crop128_bs8", "int16_texture", "phantom512_s1"])
+def test_block_partition_matches_reference(hip, name):
+    """role[] from the kernel == BLOCK_JUMPS of the reference's BlockPartitioner (cluster.py:166)."""
+    from cct_hip import DeviceBuffer, codec_params, encode_payload_dev
+    from cct_hip.batch import payload_stride
+    case = CASES[name]
+    img = np.ascontiguousarray(gi.build_input(case["input"]))
+    cfg = _config(case)
+    w, h = img.shape
+    bs = cfg["block_size"]
+    nb = w * h // bs
+    d_img = DeviceBuffer.from_numpy(img)
+    d_pay = DeviceBuffer(payload_stride(w, h, bs))
+    d_sz, d_st, d_roles = DeviceBuffer(4), DeviceBuffer(4), DeviceBuffer(nb)
+    encode_payload_dev(d_img, 1, w, h, codec_params(cfg, img.dtype), d_pay, d_sz, d_st, None, d_roles)
+    roles = d_roles.download(np.uint8, nb)
+    jumps = sorted((int(b), int(b) + int(r)) for b, r in enumerate(roles) if 0 < r < 0xFF)
+    assert len(jumps) == case["tokens"]["jump"]
+    assert hashlib.sha1(np.array(jumps, dtype=np.int32).tobytes()).hexdigest() == case["jumps_sha1"]
+    partners = {p for _, p in jumps}
+    assert partners == {int(b) for b, r in enumerate(roles) if r == 0xFF}
+
+
+def test_batch_matches_oracle_and_roundtrips(hip):
+    """A mixed batch (phantoms + both real slices) through encode_batch/decode_batch vs the oracle."""
+    from oracle import oracle
+    cfg = hip.default_config()
+    imgs = [gi.ct_phantom(s) for s in (3, 4, 5, 6, 7, 8)] + [gi.load_slice("slice0671"), gi.load_slice("slice3706")]
+    batch = np.stack(imgs)
+    files, info = hip.encode_batch(batch, cfg, return_info=True)
+    for img, f, st in zip(imgs, files, info):
+        ref, rst = oracle.encode(img, return_stats=True)
+        assert f == ref
+        assert (st["n_short"], st["n_full"], st["n_jump"], st["n_difficult"], st["payload_len"]) == \
+               (rst.n_short, rst.n_full, rst.n_jump, rst.n_difficult, rst.payload_len)
+        assert not st["q7"]
+    dec = hip.decode_batch(files, cfg)
+    assert dec.dtype == np.uint16 and dec.shape == batch.shape
+    assert np.array_equal(dec, batch)
+
+
+def _decode_like_oracle(hip, cfg, blob, bs=16):
+    """Decode one file on the GPU and on the oracle: same bytes, or the same failure (the format
+    cannot carry deltas outside [-2047, 2048] -- Q7 -- and the reference then decodes garbage or
+    raises OverflowError; the HIP decoder must do exactly the same)."""
+    from oracle import oracle
+    try:
+        want = oracle.decode(blob, block_size=bs)
+    except oracle.OracleError as e:
+        assert e.code == oracle.E_OVERFLOW
+        with pytest.raises(OverflowError):
+            hip.decode_batch([blob], cfg)
+        return None
+    got = hip.decode_batch([blob], cfg)[0].tobytes()
+    assert got == want
+    return got
+
+
+@pytest.mark.parametrize("flags", [(1, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)])
+@pytest.mark.parametrize("bs", [4, 8, 16, 32, 64])
+def test_flag_and_block_size_matrix_vs_oracle(hip, flags, bs):
+    from oracle import oracle
+    cfg = hip.default_config()
+    cfg["block_size"] = bs
+    tr = cfg["encoder"]["transforms"]
+    tr["fractal"], tr["segmentation"], cfg["encoder"]["deflate_compression"] = map(bool, flags)
+    rng = np.random.default_rng(bs * 8 + flags[0] * 4 + flags[1] * 2 + flags[2])
+    base = gi.ct_phantom(11, 128).astype(np.int32)
+    imgs = np.stack([np.clip(base + rng.integers(-40, 40, size=base.shape) * (k % 3), 0, 4095).astype(np.uint16)
+                     for k in range(5)])
+    files = hip.encode_batch(imgs, cfg)
+    for img, f in zip(imgs, files):
+        assert f == oracle.encode(img, block_size=bs, fractal=bool(flags[0]), segmentation=bool(flags[1]),
+                                  deflate=bool(flags[2]))
+        _decode_like_oracle(hip, cfg, f, bs)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (4, 4), (20, 20), (7 * 16, 9), (48, 80), (80, 48), (100, 64), (1, 32),
+                                   (32, 1), (768, 16)])
+def test_odd_shapes_vs_oracle(hip, shape):
+    from oracle import oracle
+    cfg = hip.default_config()
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(900, 1100, size=shape).astype(np.uint16)
+    f = hip.encode_batch(img[None], cfg)[0]
+    assert f == oracle.encode(img)
+    assert oracle.decode(f) == img.tobytes()
+    assert hip.decode_batch([f], cfg)[0].tobytes() == img.tobytes()
+
+
+def test_every_block_difficult_spills_lists(hip):
+    """Noise slices: every block is difficult, so the difficult-block list overflows its LDS part
+    (ENC_LIST_CAP) into the HBM workspace, and decode's jump list does likewise."""
+    from oracle import oracle
+    cfg = hip.default_config()
+    rng = np.random.default_rng(99)
+    imgs = rng.integers(0, 2048, size=(3, 256, 256)).astype(np.uint16)
+    files, info = hip.encode_batch(imgs, cfg, return_info=True)
+    for img, f, st in zip(imgs, files, info):
+        assert f == oracle.encode(img)
+        assert st["n_difficult"] > 3000 and st["n_jump"] > 1000
+    assert np.array_equal(hip.decode_batch(files, cfg), imgs)
+
+
+def test_large_slice_role_table_in_hbm(hip):
+    """1024x1024 with block_size 4: 262144 blocks -> role[] lives in the HBM workspace."""
+    from oracle import oracle
+    cfg = hip.default_config()
+    cfg["block_size"] = 4
+    img = gi.ct_phantom(21, 1024)
+    f = hip.encode_batch(img[None], cfg)[0]
+    assert f == oracle.encode(img, block_size=4)
+    assert hip.decode_batch([f], cfg)[0].tobytes() == img.tobytes()
+
+
+def test_errors_mirror_reference(hip):
+    from codec.core import Decoder, Encoder
+    from cct_hip._ffi import CorruptStreamError
+    cfg = hip.default_config()
+    cfg["verbose"] = False
+    img = gi.ct_phantom(1, 64)
+    good = Encoder(cfg, img).encode()
+    with pytest.raises(ValueError, match="valid header"):
+        Decoder(cfg, b"nope" + good[4:]).decode()
+    with pytest.raises(zlib.error):
+        Decoder(cfg, good[:13] + b"\x00\x01\x02" + good[16:]).decode()
+    with pytest.raises(ValueError):  # 100 % 16 != 0 -> reshape ValueError
+        Encoder(cfg, np.zeros((10, 10), np.uint16)).encode()
+    c2 = copy.deepcopy(cfg)
+    c2["encoder"]["transforms"]["delta"] = False
+    with pytest.raises(NotImplementedError):
+        Encoder(c2, img).encode()
+    c3 = copy.deepcopy(cfg)
+    c3["encoder"]["transforms"]["zipper"] = True
+    with pytest.raises(NotImplementedError):
+        Encoder(c3, img).encode()
+    with pytest.raises(TypeError):
+        Encoder(cfg, img.astype(np.int32)).encode()
+    # truncated raw token stream
+    c4 = copy.deepcopy(cfg)
+    c4["encoder"]["deflate_compression"] = False
+    raw = Encoder(c4, img).encode()
+    with pytest.raises(CorruptStreamError):
+        Decoder(c4, raw[: len(raw) // 2]).decode()
+
+
+def test_encoder_decoder_files_and_preview(hip, tmp_path):
+    """scripts/demo.py's flow: encode to a file, decode to a PNG preview, zero error, equal SHA-1."""
+    from PIL import Image
+    from codec.core import Decoder, Encoder
+    cfg = hip.default_config()
+    cfg["verbose"] = True
+    img = gi.load_slice("slice0671")
+    cct = tmp_path / "testing.cct"
+    out = Encoder(cfg, img, str(cct)).encode()
+    assert cct.read_bytes() == out
+    png = tmp_path / "decoded-testing.png"
+    dec = Decoder(cfg, cct.read_bytes(), str(png))
+    pixels = dec.decode()
+    assert pixels.shape == (512, 512) and pixels.dtype == np.uint16
+    assert np.count_nonzero(img - pixels) == 0
+    assert hashlib.sha1(img.tobytes()).hexdigest() == hashlib.sha1(pixels.tobytes()).hexdigest()
+    assert (dec.width, dec.height, dec.channels, dec.bytes_per_channel) == (512, 512, 1, 2)
+    assert dec.fractal_transform and dec.segmentation_transform and dec.deflate_compression
+    prev = np.array(Image.open(png))
+    assert np.array_equal(prev.astype(np.uint32), img.astype(np.uint32) << 4)
+
+
+def test_full_batch_properties(hip):
+    """BASELINE config 2 size (256 x 512x512): round trip is the identity, payload length equals
+    N + n_full + n_jump + 1, and a checksum of checksums matches the oracle on a sample."""
+    from oracle import oracle
+    from cct_hip import DeviceBuffer, codec_params, decode_payload_dev, encode_payload_dev
+    from cct_hip.batch import payload_stride
+    from cct_hip._ffi import SliceStats
+    import ctypes as C
+    cfg = hip.default_config()
+    n, w, h, bs = 256, 512, 512, 16
+    base = [gi.ct_phantom(s) for s in range(32)]
+    sym = [lambda a: a, np.fliplr, np.flipud, lambda a: a.T, lambda a: np.fliplr(a).T, lambda a: np.flipud(a).T,
+           lambda a: np.flipud(np.fliplr(a)), lambda a: np.flipud(np.fliplr(a)).T]
+    imgs = np.stack([np.ascontiguousarray(sym[i // 32](base[i % 32])) for i in range(n)])
+    stride = payload_stride(w, h, bs)
+    d_img = DeviceBuffer.from_numpy(imgs)
+    d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+    d_stats = DeviceBuffer(16 * n)
+    d_out = DeviceBuffer(imgs.nbytes)
+    params = codec_params(cfg, imgs.dtype)
+    encode_payload_dev(d_img, n, w, h, params, d_pay, d_sz, d_st, d_stats)
+    sizes = d_sz.download(np.uint32, n)
+    est = d_st.download(np.uint32, n)
+    assert not (est & ~np.uint32(1)).any()  # only the informational Q7 bit may be set
+    clean = est == 0
+    assert clean.sum() >= n - 8
+    stats = d_stats.download(np.uint32, 4 * n).reshape(n, 4)
+    assert np.array_equal(sizes, w * h + stats[:, 1] + stats[:, 2] + 1)
+    assert np.array_equal(stats[:, 0] + stats[:, 1], np.full(n, w * h))
+    d_out.zero()
+    decode_payload_dev(d_pay, stride, d_sz, n, w, h, bs, True, d_out, d_st)
+    dst = d_st.download(np.uint32, n)
+    assert not dst[clean].any()
+    back = d_out.download(np.uint16, n * w * h).reshape(n, w, h)
+    assert np.array_equal(back[clean], imgs[clean])
+    for i in (0, 17, 100, 255):
+        pay = d_pay.download(np.uint8, int(sizes[i]), offset=i * stride).tobytes()
+        assert oracle.encode(imgs[i], deflate=False)[13:] == pay
