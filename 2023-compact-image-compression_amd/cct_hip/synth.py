@@ -6,8 +6,11 @@ exercise the same code paths as real slices: smooth tissue (short tokens),
 edges (full tokens) and textured bone (difficult blocks -> mesh jumps).
 
 Format constraint: the .cct format only carries
-traversal deltas in [-2047, 2048]; the phantom keeps bone inside soft tissue so
-no air|bone adjacency exists.
+traversal deltas in [-2047, 2048], and the mesh step may interleave any two
+blocks up to 63 apart, so adjacency arguments are not enough.  The phantom
+therefore keeps every sample in [0, 2047] (bone at 1500-1750 plus texture,
+instead of Appendix D's 1900-2200): then no delta can leave the range, whatever
+order the encoder picks, and every slice round-trips.
 """
 import numpy as np
 
@@ -57,7 +60,7 @@ def ct_phantom(seed, n=512):
     spine = ((u - sx) / 0.085) ** 2 + ((v - sy) / 0.10) ** 2 <= 1.0
     spine &= rb < 0.92
     bone = ribs | spine
-    img[bone] = rng.uniform(1900.0, 2200.0)
+    img[bone] = rng.uniform(1500.0, 1750.0)
 
     # thin table arc below the body
     rt = np.sqrt(u * u + (v - 1.75) ** 2)
@@ -81,7 +84,7 @@ def ct_phantom(seed, n=512):
     img += np.where(dil, tex, 0.0)
 
     img[~fov] = 0.0
-    return np.clip(np.rint(img), 0, 4095).astype(np.uint16)
+    return np.clip(np.rint(img), 0, 2047).astype(np.uint16)
 
 
 def ct_batch(seeds, n=512):

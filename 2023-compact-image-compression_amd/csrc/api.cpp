@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,16 @@ struct Context {
 	DevBuf h_stage;  // pinned host staging (payloads)
 	int zlib_threads = 0;
 	int wg_threads = 1024;
+	// timings of the most recent batch call (cct_last_timings)
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+	float t_enc_kernel_ms = 0, t_dec_kernel_ms = 0, t_d2h_ms = 0, t_deflate_ms = 0, t_inflate_ms = 0, t_h2d_ms = 0;
 };
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
 
 Context g_ctx;
 std::mutex g_mu;
@@ -112,6 +122,8 @@ int ensure_ctx(int device = -1)
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 		return fail(CCT_E_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
 	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_k0));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_k1));
 	g_ctx.h_stage.pinned_host = true;
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
@@ -245,6 +257,8 @@ int cct_shutdown(void)
 	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
 	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage};
 	for (DevBuf *b : bufs) b->release();
+	(void)hipEventDestroy(g_ctx.ev_k0);
+	(void)hipEventDestroy(g_ctx.ev_k1);
 	(void)hipStreamDestroy(g_ctx.stream);
 	g_ctx = Context();
 	return CCT_OK;
@@ -411,16 +425,20 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	if ((rc = g_ctx.e_status.ensure((size_t)n * 4))) return rc;
 	if ((rc = g_ctx.h_stage.ensure((size_t)n * stride))) return rc;
 	if ((rc = g_ctx.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
+	HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
 	rc = encode_payload_locked(d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)g_ctx.e_payload.p, stride,
 	                           (uint32_t *)g_ctx.e_sizes.p, (uint32_t *)g_ctx.e_status.p,
 	                           h_stats ? (cct_slice_stats *)g_ctx.e_stats.p : nullptr, nullptr);
 	if (rc) return rc;
+	HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
 	if (h_stats)
 		HIP_TRY(hipMemcpyAsync(h_stats, g_ctx.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, g_ctx.stream));
 	std::vector<uint32_t> psz(n);
 	HIP_TRY(hipMemcpyAsync(psz.data(), g_ctx.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipMemcpyAsync(h_status, g_ctx.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipEventElapsedTime(&g_ctx.t_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+	const double t_copy0 = now_ms();
 	// bring back only the bytes each slice produced
 	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
 	for (int i = 0; i < n; i++) {
@@ -429,6 +447,8 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 		                       hipMemcpyDeviceToHost, g_ctx.stream));
 	}
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	const double t_defl0 = now_ms();
+	g_ctx.t_d2h_ms = (float)(t_defl0 - t_copy0);
 
 	std::atomic<int> zerr(0);
 	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
@@ -452,6 +472,7 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 			h_out_sizes[i] = 13 + psz[i];
 		}
 	});
+	g_ctx.t_deflate_ms = (float)(now_ms() - t_defl0);
 	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
 	return CCT_OK;
@@ -512,6 +533,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	std::vector<uint32_t> psz(n);
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
 	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421
+	const double t_inf0 = now_ms();
 	parallel_for(n, h0.deflate ? g_ctx.zlib_threads : 1, [&](int i) {
 		const uint8_t *body = h_files + h_offsets[i] + 13;
 		const size_t blen = (size_t)(h_offsets[i + 1] - h_offsets[i]) - 13;
@@ -527,6 +549,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 			else { memcpy(dst, body, blen); psz[i] = (uint32_t)blen; }
 		}
 	});
+	g_ctx.t_inflate_ms = (float)(now_ms() - t_inf0);
 	for (int i = 0; i < n; i++)
 		HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.d_payload.p + (size_t)i * stride, stage + (size_t)i * stride,
 		                       (psz[i] + 15u) & ~15u, hipMemcpyHostToDevice, g_ctx.stream));
@@ -536,14 +559,17 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		if ((rc = g_ctx.d_images.ensure((size_t)n * N * 2))) return rc;
 		d_img = (uint16_t *)g_ctx.d_images.p;
 	}
+	HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
 	rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
 	                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p);
 	if (rc) return rc;
+	HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
 	std::vector<uint32_t> dst(n);
 	HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	if (!images_on_device)
 		HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
 	int first = CCT_OK;
 	for (int i = 0; i < n; i++) {
 		if (h_status[i] == CCT_OK) {
@@ -559,6 +585,14 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		}
 	}
 	return first;
+}
+
+int cct_last_timings(float *out6)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	out6[0] = g_ctx.t_enc_kernel_ms; out6[1] = g_ctx.t_d2h_ms; out6[2] = g_ctx.t_deflate_ms;
+	out6[3] = g_ctx.t_inflate_ms; out6[4] = g_ctx.t_dec_kernel_ms; out6[5] = g_ctx.t_h2d_ms;
+	return CCT_OK;
 }
 
 int cct_set_option(const char *key, int value)

@@ -1,0 +1,66 @@
+"""N>1 path on CPU: world_size-2 gloo process group exercising shard_range / gather_sizes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "2023-compact-image-compression_amd")
+
+WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, {pkg!r})
+import torch.distributed as dist
+from cct_hip.parallel import shard_range, gather_sizes, file_offsets
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_total = 3954 if len(sys.argv) < 2 else int(sys.argv[1])
+lo, hi = shard_range(n_total, rank, world)
+sizes = (np.arange(lo, hi, dtype=np.uint32) * 7 + 150000) % 244138
+allsz = gather_sizes(sizes, dist, 0)
+expect = (np.arange(n_total, dtype=np.uint32) * 7 + 150000) % 244138
+assert allsz.dtype == np.uint32 and np.array_equal(allsz, expect), (rank, allsz[:4], expect[:4])
+offs = file_offsets(allsz)
+assert offs[-1] == expect.astype(np.uint64).sum() and offs[lo] == expect[:lo].astype(np.uint64).sum()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", lo, hi)
+"""
+
+
+def _run(world, n_total):
+    code = WORKER.format(pkg=PKG)
+    procs = []
+    port = 29500 + (os.getpid() % 2000)
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code, str(n_total)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    return outs
+
+
+def test_gather_sizes_world2_corpus_shards():
+    outs = _run(2, 3954)  # BASELINE config 3: 3954 slices, 1977 per rank
+    assert "ok 0 1977" in outs[0] and "ok 1977 3954" in outs[1]
+
+
+def test_gather_sizes_world2_ragged():
+    _run(2, 7)  # 4 + 3 slices: padded collective, trimmed result
+
+
+def test_shard_range_covers_everything():
+    from cct_hip.parallel import shard_range
+    for n in (0, 1, 7, 256, 3954):
+        for world in (1, 2, 4, 8):
+            got = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                got.extend(range(lo, hi))
+            assert got == list(range(n))
+    assert shard_range(3954, 0, 8) == (0, 495) and shard_range(3954, 7, 8) == (3465, 3954)
