@@ -64,12 +64,22 @@ struct DevBuf {  // grow-only device (or pinned host) buffer
 	}
 };
 
+struct ShapeTables {  // everything that depends on (width, height) only; lives in HBM
+	int32_t *d_lut = nullptr;  // traversal order O[N]
+	bool tiled = false;        // traversal = aligned 64x64 tiles -> encode_tiles_kernel applies
+	int n_tiles = 0, n_orient = 0;
+	uint32_t *d_org = nullptr;
+	uint8_t *d_orient = nullptr;
+	uint16_t *d_pat = nullptr;
+};
+
 struct Context {
 	bool ready = false;
 	pid_t pid = 0;
 	int device = -1;
 	hipStream_t stream = nullptr;
-	std::map<std::pair<int, int>, int32_t *> luts;  // (width,height) -> device traversal table
+	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
+	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
 	// decode workspaces
@@ -135,19 +145,79 @@ int ensure_ctx(int device = -1)
 	return CCT_OK;
 }
 
-int get_lut(int width, int height, const int32_t **out)
+// Does the traversal decompose into aligned 64x64 tiles (4096 consecutive positions each)?  If so
+// build what encode_tiles_kernel needs: per tile its origin and which pattern it follows, and per
+// distinct pattern the LDS byte offset (row-XOR-swizzled raster image) of every position.
+void build_tile_tables(const std::vector<int32_t> &O, int width, ShapeTables &t)
+{
+	t.tiled = false;
+	const size_t N = O.size();
+	if (N == 0 || N % 8192 != 0 || width % 8 != 0) return;
+	const int nt = (int)(N / 4096);
+	if (nt > TILE_MAX_TILES) return;
+	std::vector<uint32_t> org(nt);
+	std::vector<uint8_t> orient(nt);
+	std::vector<std::vector<uint16_t>> pats;
+	std::vector<uint16_t> cur(4096);
+	for (int ti = 0; ti < nt; ti++) {
+		const int32_t *k = O.data() + (size_t)ti * 4096;
+		int32_t lo = k[0];
+		for (int i = 1; i < 4096; i++) lo = std::min(lo, k[i]);
+		if ((lo % width) % 8 != 0) return;
+		for (int i = 0; i < 4096; i++) {
+			const int32_t d = k[i] - lo;
+			const int dy = d / width, dx = d % width;
+			if (dx >= 64 || dy >= 64) return;  // not an aligned 64x64 square
+			cur[i] = (uint16_t)(dy * 128 + (((dx >> 3) ^ (dy & 7)) << 4) + (dx & 7) * 2);
+		}
+		int which = -1;
+		for (size_t p = 0; p < pats.size(); p++)
+			if (pats[p] == cur) { which = (int)p; break; }
+		if (which < 0) {
+			if ((int)pats.size() == TILE_MAX_ORIENT) return;
+			pats.push_back(cur);
+			which = (int)pats.size() - 1;
+		}
+		org[ti] = (uint32_t)lo;
+		orient[ti] = (uint8_t)which;
+	}
+	std::vector<uint16_t> flat;
+	for (auto &p : pats) flat.insert(flat.end(), p.begin(), p.end());
+	if (hipMalloc(&t.d_org, nt * sizeof(uint32_t)) != hipSuccess) return;
+	if (hipMalloc(&t.d_orient, nt) != hipSuccess) return;
+	if (hipMalloc(&t.d_pat, flat.size() * sizeof(uint16_t)) != hipSuccess) return;
+	if (hipMemcpy(t.d_org, org.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_orient, orient.data(), nt, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_pat, flat.data(), flat.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return;
+	t.n_tiles = nt;
+	t.n_orient = (int)pats.size();
+	t.tiled = true;
+}
+
+int get_tables(int width, int height, const ShapeTables **out)
 {
 	auto key = std::make_pair(width, height);
 	auto it = g_ctx.luts.find(key);
-	if (it != g_ctx.luts.end()) { *out = it->second; return CCT_OK; }
+	if (it != g_ctx.luts.end()) { *out = &it->second; return CCT_OK; }
 	const size_t N = (size_t)width * height;
 	std::vector<int32_t> host(N ? N : 1);
 	if (!gilbert_table(width, height, host.data())) return fail(CCT_E_SHAPE, "traversal generation failed for %dx%d", width, height);
-	int32_t *d = nullptr;
-	HIP_TRY(hipMalloc(&d, (N ? N : 1) * sizeof(int32_t)));
-	HIP_TRY(hipMemcpy(d, host.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
-	g_ctx.luts[key] = d;
-	*out = d;
+	host.resize(N);
+	ShapeTables t;
+	HIP_TRY(hipMalloc(&t.d_lut, (N ? N : 1) * sizeof(int32_t)));
+	HIP_TRY(hipMemcpy(t.d_lut, host.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+	build_tile_tables(host, width, t);
+	auto ins = g_ctx.luts.emplace(key, t);
+	*out = &ins.first->second;
+	return CCT_OK;
+}
+
+int get_lut(int width, int height, const int32_t **out)
+{
+	const ShapeTables *t;
+	int rc = get_tables(width, height, &t);
+	if (rc) return rc;
+	*out = t->d_lut;
 	return CCT_OK;
 }
 
@@ -203,6 +273,20 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	if ((rc = g_ctx.e_lmask.ensure(per * 8))) return rc;
 	if ((rc = g_ctx.e_lcur.ensure(per))) return rc;
 	a.ws_lidx = (uint32_t *)g_ctx.e_lidx.p; a.ws_lmask = (uint64_t *)g_ctx.e_lmask.p; a.ws_lcur = (uint8_t *)g_ctx.e_lcur.p;
+	const ShapeTables *tb = nullptr;
+	if ((flags & CCT_FLAG_FRACTAL) && bs == 16 && g_ctx.use_tiles) { if ((rc = get_tables(width, height, &tb))) return rc; }
+	if (tb && tb->tiled) {
+		bool tile_role_in_lds = true;
+		(void)enc_tiles_lds_bytes(NB, &tile_role_in_lds);
+		if (!tile_role_in_lds) { if ((rc = g_ctx.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)g_ctx.e_role.p; }
+		else a.ws_role = nullptr;
+		TileEncArgs ta{};
+		ta.e = a;
+		ta.tile_org = tb->d_org; ta.tile_orient = tb->d_orient; ta.patterns = tb->d_pat;
+		ta.n_orient = tb->n_orient; ta.n_tiles = tb->n_tiles; ta.row_pitch = width;
+		HIP_TRY(launch_encode_tiles(ta, n, g_ctx.stream));
+		return CCT_OK;
+	}
 	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
 	return CCT_OK;
 }
@@ -252,7 +336,7 @@ int cct_shutdown(void)
 	if (!g_ctx.ready || g_ctx.pid != getpid()) { g_ctx = Context(); return CCT_OK; }
 	(void)hipSetDevice(g_ctx.device);
 	(void)hipStreamSynchronize(g_ctx.stream);
-	for (auto &kv : g_ctx.luts) (void)hipFree(kv.second);
+	for (auto &kv : g_ctx.luts) { (void)hipFree(kv.second.d_lut); (void)hipFree(kv.second.d_org); (void)hipFree(kv.second.d_orient); (void)hipFree(kv.second.d_pat); }
 	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
 	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
 	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage};
@@ -599,6 +683,7 @@ int cct_set_option(const char *key, int value)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
+	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -609,6 +694,7 @@ int cct_get_option(const char *key, int *value)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
+	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

@@ -33,6 +33,19 @@ struct EncArgs {
 	uint8_t *roles_out;       // optional n * NB: final role of every block (BLOCK_JUMPS)
 };
 
+// tile-staged fast path (block_size 16, traversal made of aligned 64x64 tiles)
+constexpr int TILE_MAX_TILES = 1024;
+constexpr int TILE_MAX_ORIENT = 4;
+struct TileEncArgs {
+	EncArgs e;
+	const uint32_t *tile_org;    // n_tiles: raster index of each tile's top-left pixel
+	const uint8_t *tile_orient;  // n_tiles: which pattern table the tile uses
+	const uint16_t *patterns;    // n_orient * 4096: LDS byte offset of every traversal position of a tile
+	int n_orient, n_tiles, row_pitch;
+};
+size_t enc_tiles_lds_bytes(int NB, bool *role_in_lds);
+hipError_t launch_encode_tiles(const TileEncArgs &ta, int n, hipStream_t s);
+
 size_t enc_lds_bytes(int NB, bool *role_in_lds);
 hipError_t launch_encode(const EncArgs &a, int n, int block_size, int threads, hipStream_t s);
 

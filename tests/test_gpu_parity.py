@@ -287,3 +287,40 @@ def test_full_batch_properties(hip):
     for i in (0, 17, 100, 255):
         pay = d_pay.download(np.uint8, int(sizes[i]), offset=i * stride).tobytes()
         assert oracle.encode(imgs[i], deflate=False)[13:] == pay
+
+
+@pytest.mark.parametrize("n_px", [128, 256, 512, 1024])
+def test_tile_path_equals_generic_path(hip, n_px):
+    """The tile-staged fast kernel and the generic LUT-gather kernel must agree byte for byte
+    (payload, sizes, statistics, block roles) -- and with the oracle."""
+    from oracle import oracle
+    from cct_hip import DeviceBuffer, codec_params, encode_payload_dev, _ffi
+    from cct_hip.batch import payload_stride
+    cfg = hip.default_config()
+    L = _ffi.lib()
+    n = 3
+    imgs = np.stack([gi.ct_phantom(40 + i, n_px) for i in range(n)])
+    if n_px == 256:
+        rng = np.random.default_rng(1)
+        imgs[1] = rng.integers(0, 2048, size=(256, 256))  # every block difficult: spilled lists
+    w = h = n_px
+    nb = w * h // 16
+    stride = payload_stride(w, h, 16)
+    d_img = DeviceBuffer.from_numpy(imgs)
+    res = []
+    for tile in (1, 0):
+        _ffi.check(L.cct_set_option(b"tile_path", tile))
+        d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+        d_stats, d_roles = DeviceBuffer(16 * n), DeviceBuffer(n * nb)
+        d_pay.zero()
+        encode_payload_dev(d_img, n, w, h, codec_params(cfg, imgs.dtype), d_pay, d_sz, d_st, d_stats, d_roles)
+        sizes = d_sz.download(np.uint32, n)
+        res.append((sizes, d_st.download(np.uint32, n), d_stats.download(np.uint32, 4 * n),
+                    d_roles.download(np.uint8, n * nb),
+                    [d_pay.download(np.uint8, int(sizes[i]), offset=i * stride).tobytes() for i in range(n)]))
+    _ffi.check(L.cct_set_option(b"tile_path", 1))
+    for a_, b_ in zip(res[0][:4], res[1][:4]):
+        assert np.array_equal(a_, b_)
+    assert res[0][4] == res[1][4]
+    for i in range(n):
+        assert res[0][4][i] == oracle.encode(imgs[i], deflate=False)[13:]
