@@ -80,6 +80,7 @@ struct Context {
 	hipStream_t stream = nullptr;
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
+	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
 	// decode workspaces
@@ -264,6 +265,7 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	a.N = N; a.NB = NB; a.eof = eof; a.flags = flags;
 	a.payload = d_payload; a.stride = stride; a.sizes = d_sizes; a.status = d_status;
 	a.stats = reinterpret_cast<uint32_t *>(d_stats); a.roles_out = d_roles;
+	a.dbg_skip = (uint32_t)g_ctx.dbg_skip;
 	bool role_in_lds = true;
 	(void)enc_lds_bytes(NB, &role_in_lds);
 	const size_t per = (size_t)n * NB;
@@ -684,6 +686,7 @@ int cct_set_option(const char *key, int value)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;

@@ -31,6 +31,7 @@ struct EncArgs {
 	uint8_t *ws_lcur;         // n * NB spill: cur counts
 	uint32_t *stats;          // optional n * 4: short, full, jump tokens, difficult blocks
 	uint8_t *roles_out;       // optional n * NB: final role of every block (BLOCK_JUMPS)
+	uint32_t dbg_skip;        // tuning only (option "debug_skip"): phases to skip, results then invalid
 };
 
 // tile-staged fast path (block_size 16, traversal made of aligned 64x64 tiles)

@@ -199,7 +199,7 @@ def main():
                                    f"encode to .cct + decode back, {N_ROT} rotating device-resident batches",
                        "slices_per_gpu": n, "width": W, "height": H, "block_size": bs,
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)"},
-            "roofline": {"kernel": "encode_kernel<16> (transform+pack, image -> token payload)", "bound": "hbm",
+            "roofline": {"kernel": "encode_tiles_kernel (transform+pack, image -> token payload)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
