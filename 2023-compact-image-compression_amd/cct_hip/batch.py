@@ -212,3 +212,23 @@ def decode_batch(files, config=None, out_dev=None):
     rc = L.cct_decode_batch(blob, offs.ctypes.data, n, bs, magic, out.ctypes.data, 0, out.size, status.ctypes.data)
     _ffi.check(rc)
     return out
+
+
+def zlib_compress_batch(blobs):
+    """DEFLATE stage alone on the device: [bytes] -> [zlib streams], each byte-identical to
+    zlib.compress(blob, level=9) (what the reference calls at core.py:340)."""
+    import zlib
+    L = _ffi.lib()
+    n = len(blobs)
+    if n == 0:
+        return []
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in blobs], out=offs[1:])
+    data = b"".join(blobs) or b"\0"
+    longest = max(len(b) for b in blobs)
+    in_stride = (longest + 16 + 255) & ~255
+    out_stride = (len(zlib.compress(b"", 0)) + in_stride + (in_stride >> 12) + (in_stride >> 14) + (in_stride >> 25) + 13 + 128 + 63) & ~63
+    out = np.empty((n, out_stride), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    _ffi.check(L.cct_zlib_compress_batch(data, offs.ctypes.data, n, out.ctypes.data, out_stride, sizes.ctypes.data))
+    return [out[i, : sizes[i]].tobytes() for i in range(n)]

@@ -86,6 +86,12 @@ struct Context {
 	// decode workspaces
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images;
 	DevBuf h_stage;  // pinned host staging (payloads)
+	// device DEFLATE workspaces
+	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
+	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes;
+	bool z_tables_ready = false;
+	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
+	float t_dev_deflate_ms = 0;
 	int zlib_threads = 0;
 	int wg_threads = 1024;
 	// timings of the most recent batch call (cct_last_timings)
@@ -293,6 +299,55 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	return CCT_OK;
 }
 
+// DEFLATE (zlib level 9 stream) of n device-resident byte strings on the device; output slice i =
+// 13 header bytes + zlib stream at d_out + i*out_stride (g_ctx.z_out), sizes in g_ctx.z_outsizes.
+int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_sizes, int n, const uint8_t header13[13],
+                   size_t out_stride)
+{
+	if (in_stride % 256 != 0 || out_stride % 4 != 0) return fail(CCT_E_ARG, "deflate strides must be multiples of 256 / 4");
+	const size_t E = (size_t)n * in_stride;
+	if (E >= ((size_t)1 << 32)) return fail(CCT_E_ARG, "deflate batch of %zu bytes exceeds the 4 GiB sort limit; split the batch", E);
+	if (!g_ctx.z_tables_ready) { HIP_TRY(deflate_init_tables()); g_ctx.z_tables_ready = true; }
+	const int max_blocks = (int)(in_stride / 16383 + 2);
+	int rc;
+	if ((rc = g_ctx.z_keys_in.ensure(E * 2))) return rc;
+	if ((rc = g_ctx.z_keys_out.ensure(E * 2))) return rc;
+	if ((rc = g_ctx.z_vals_in.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_vals_out.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_mr.ensure(E * 8))) return rc;
+	if ((rc = g_ctx.z_rec.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_exitp.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_exitc.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_sym.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_bentry.ensure(E / 64 * 4))) return rc;
+	if ((rc = g_ctx.z_bsym.ensure(E / 64 * 4))) return rc;
+	if ((rc = g_ctx.z_small.ensure((size_t)n * 6 * 4))) return rc;
+	if ((rc = g_ctx.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
+	if ((rc = g_ctx.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
+	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
+	if ((rc = g_ctx.z_out.ensure((size_t)n * out_stride))) return rc;
+	if ((rc = g_ctx.z_outsizes.ensure((size_t)n * 4))) return rc;
+	const size_t tmp = deflate_sort_temp_bytes(E, n);
+	if ((rc = g_ctx.z_sorttmp.ensure(tmp + 256))) return rc;
+	DeflateArgs a{};
+	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
+	a.keys_in = (uint16_t *)g_ctx.z_keys_in.p; a.keys_out = (uint16_t *)g_ctx.z_keys_out.p;
+	a.vals_in = (uint32_t *)g_ctx.z_vals_in.p; a.vals_out = (uint32_t *)g_ctx.z_vals_out.p;
+	uint32_t *small = (uint32_t *)g_ctx.z_small.p;
+	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
+	a.n_blocks = small + 4 * n; a.adler = small + 5 * n;
+	a.mr = g_ctx.z_mr.p; a.rec32 = (uint32_t *)g_ctx.z_rec.p;
+	a.exit_pos = (uint32_t *)g_ctx.z_exitp.p; a.exit_cnt = (uint32_t *)g_ctx.z_exitc.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
+	a.blk_entry = (uint32_t *)g_ctx.z_bentry.p; a.blk_symbase = (uint32_t *)g_ctx.z_bsym.p;
+	a.blk_end = (uint32_t *)g_ctx.z_bend.p;
+	a.block_meta = (BlockMeta *)g_ctx.z_meta.p; a.block_tables = (BlockTables *)g_ctx.z_tables.p;
+	a.max_blocks = max_blocks;
+	a.out = (uint8_t *)g_ctx.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)g_ctx.z_outsizes.p;
+	memcpy(a.header13, header13, 13);
+	HIP_TRY(launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream));
+	return CCT_OK;
+}
+
 int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_t *d_sizes, int n, int width,
                           int height, int bs, int fractal, uint16_t *d_images, uint32_t *d_status)
 {
@@ -341,7 +396,10 @@ int cct_shutdown(void)
 	for (auto &kv : g_ctx.luts) { (void)hipFree(kv.second.d_lut); (void)hipFree(kv.second.d_org); (void)hipFree(kv.second.d_orient); (void)hipFree(kv.second.d_pat); }
 	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
 	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
-	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage};
+	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage,
+	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
+	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
+	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes};
 	for (DevBuf *b : bufs) b->release();
 	(void)hipEventDestroy(g_ctx.ev_k0);
 	(void)hipEventDestroy(g_ctx.ev_k1);
@@ -524,6 +582,36 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	HIP_TRY(hipMemcpyAsync(h_status, g_ctx.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 	HIP_TRY(hipEventElapsedTime(&g_ctx.t_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+	uint8_t hdr13[13];  // core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
+	hdr13[0] = (uint8_t)magic[0]; hdr13[1] = (uint8_t)magic[1]; hdr13[2] = (uint8_t)magic[2]; hdr13[3] = (uint8_t)magic[3];
+	hdr13[4] = (uint8_t)((width >> 8) & 0xFF); hdr13[5] = (uint8_t)(width & 0xFF);
+	hdr13[6] = (uint8_t)((height >> 8) & 0xFF); hdr13[7] = (uint8_t)(height & 0xFF);
+	hdr13[8] = (uint8_t)(channels & 0xFF); hdr13[9] = (uint8_t)(bytes_per_channel & 0xFF);
+	hdr13[10] = (flags & CCT_FLAG_FRACTAL) ? 1 : 0;
+	hdr13[11] = (flags & CCT_FLAG_SEGMENTATION) ? 1 : 0;
+	hdr13[12] = defl ? 1 : 0;
+	if (defl && g_ctx.device_deflate) {
+		// DEFLATE on the device: zlib.compress(data, level=9) (core.py:340) restated in deflate_kernels.hip
+		for (int i = 0; i < n; i++)
+			if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
+		const size_t zstride = cct_file_bound(width, height, block_size);
+		HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
+		rc = deflate_locked((const uint8_t *)g_ctx.e_payload.p, stride, (const uint32_t *)g_ctx.e_sizes.p, n, hdr13, zstride);
+		if (rc) return rc;
+		HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
+		HIP_TRY(hipMemcpyAsync(h_out_sizes, g_ctx.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+		g_ctx.t_deflate_ms = g_ctx.t_dev_deflate_ms;
+		const double t_c0 = now_ms();
+		for (int i = 0; i < n; i++)
+			HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.z_out.p + (size_t)i * zstride, h_out_sizes[i],
+			                       hipMemcpyDeviceToHost, g_ctx.stream));
+		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		g_ctx.t_d2h_ms = (float)(now_ms() - t_c0);
+		if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
+		return CCT_OK;
+	}
 	const double t_copy0 = now_ms();
 	// bring back only the bytes each slice produced
 	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
@@ -539,14 +627,7 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	std::atomic<int> zerr(0);
 	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
 		uint8_t *o = h_out + (size_t)i * out_stride;
-		// 13-byte header, core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
-		o[0] = (uint8_t)magic[0]; o[1] = (uint8_t)magic[1]; o[2] = (uint8_t)magic[2]; o[3] = (uint8_t)magic[3];
-		o[4] = (uint8_t)((width >> 8) & 0xFF); o[5] = (uint8_t)(width & 0xFF);
-		o[6] = (uint8_t)((height >> 8) & 0xFF); o[7] = (uint8_t)(height & 0xFF);
-		o[8] = (uint8_t)(channels & 0xFF); o[9] = (uint8_t)(bytes_per_channel & 0xFF);
-		o[10] = (flags & CCT_FLAG_FRACTAL) ? 1 : 0;
-		o[11] = (flags & CCT_FLAG_SEGMENTATION) ? 1 : 0;
-		o[12] = defl ? 1 : 0;
+		memcpy(o, hdr13, 13);
 		const uint8_t *pl = stage + (size_t)i * stride;
 		if (defl) {  // zlib.compress(data, level=9), core.py:340
 			uLongf dl = (uLongf)(out_stride - 13);
@@ -561,6 +642,45 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	g_ctx.t_deflate_ms = (float)(now_ms() - t_defl0);
 	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
+	return CCT_OK;
+}
+
+int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, uint8_t *h_out, size_t out_stride,
+                            uint32_t *h_out_sizes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	if (n == 0) return CCT_OK;
+	size_t longest = 0;
+	for (int i = 0; i < n; i++) longest = std::max(longest, (size_t)(h_offsets[i + 1] - h_offsets[i]));
+	const size_t in_stride = (longest + 16 + 255) & ~(size_t)255;
+	const size_t zstride = (13 + compressBound((uLong)in_stride) + 63) & ~(size_t)63;
+	if (out_stride < zstride - 13) return fail(CCT_E_CAP, "out_stride %zu too small (need %zu)", out_stride, zstride - 13);
+	if ((rc = g_ctx.z_in.ensure((size_t)n * in_stride))) return rc;
+	if ((rc = g_ctx.z_insizes.ensure((size_t)n * 4))) return rc;
+	std::vector<uint32_t> isz(n);
+	HIP_TRY(hipMemsetAsync(g_ctx.z_in.p, 0, (size_t)n * in_stride, g_ctx.stream));
+	for (int i = 0; i < n; i++) {
+		isz[i] = (uint32_t)(h_offsets[i + 1] - h_offsets[i]);
+		if (isz[i])
+			HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.z_in.p + (size_t)i * in_stride, h_in + h_offsets[i], isz[i],
+			                       hipMemcpyHostToDevice, g_ctx.stream));
+	}
+	HIP_TRY(hipMemcpyAsync(g_ctx.z_insizes.p, isz.data(), (size_t)n * 4, hipMemcpyHostToDevice, g_ctx.stream));
+	uint8_t hdr13[13] = {0};
+	rc = deflate_locked((const uint8_t *)g_ctx.z_in.p, in_stride, (const uint32_t *)g_ctx.z_insizes.p, n, hdr13, zstride);
+	if (rc) return rc;
+	std::vector<uint32_t> osz(n);
+	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	for (int i = 0; i < n; i++) {
+		h_out_sizes[i] = osz[i] - 13;
+		HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.z_out.p + (size_t)i * zstride + 13, osz[i] - 13,
+		                       hipMemcpyDeviceToHost, g_ctx.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 	return CCT_OK;
 }
 
@@ -687,6 +807,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
+	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -698,6 +819,7 @@ int cct_get_option(const char *key, int *value)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
+	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

@@ -67,4 +67,36 @@ struct DecArgs {
 
 hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s);
 
+// ---- device DEFLATE (zlib 1.2.11 level 9 restatement, deflate_kernels.hip) ----------------
+struct BlockMeta {          // one DEFLATE block of a slice
+	uint64_t bit_off;         // absolute bit offset of the 3 header bits inside the slice's output
+	uint32_t type;            // 0 stored, 1 static trees, 2 dynamic trees
+	uint32_t last;
+	uint32_t first_sym, nsym;
+	uint32_t in_begin, stored_len;
+	uint32_t hdr_nbits, body_bits;
+};
+struct BlockTables {
+	uint16_t lcode[286]; uint8_t llen[286];
+	uint16_t dcode[30]; uint8_t dlen[30];
+	uint32_t hdr_bits[160];
+};
+struct DeflateArgs {
+	const uint8_t *in; size_t in_stride; const uint32_t *in_sizes;  // token payloads (device)
+	uint16_t *keys_in, *keys_out; uint32_t *vals_in, *vals_out;      // n * in_stride each
+	uint32_t *seg_begin, *seg_end;                                   // n
+	void *mr;                                                        // n * in_stride * 8 bytes
+	uint32_t *rec32, *exit_pos, *exit_cnt, *sym;                     // n * in_stride each
+	uint32_t *blk_entry, *blk_symbase;                               // n * in_stride / 64
+	uint32_t *total_syms, *postloop_lit, *n_blocks, *adler;          // n
+	uint32_t *blk_end;                                               // n * max_blocks
+	BlockMeta *block_meta; BlockTables *block_tables;                // n * max_blocks
+	int max_blocks;
+	uint8_t *out; size_t out_stride; uint32_t *out_sizes;            // whole .cct files (header + zlib stream)
+	uint8_t header13[16];
+};
+hipError_t deflate_init_tables();
+size_t deflate_sort_temp_bytes(size_t total, int n);
+hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st);
+
 }  // namespace cct

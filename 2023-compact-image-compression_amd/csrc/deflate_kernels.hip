@@ -1,0 +1,752 @@
+// Device DEFLATE, byte-identical to zlib 1.2.11 `deflate(level 9, wbits 15, memLevel 8, default
+// strategy, one-shot Z_FINISH)` -- the stream CPython's zlib.compress(data, level=9) produces for
+// the reference (src/codec/core.py:340).  zlib is a third-party dependency of the reference and is
+// not vendored there; the algorithm is restated here in data-parallel form (CPU model of the same
+// restatement, pinned against libz: oracle/deflate_model.c).
+//
+//   hash      every payload position gets its 15-bit rolling hash of 3 bytes (deflate.c UPDATE_HASH)
+//   sort      stable segmented radix sort of (hash, position) per slice: a bucket in position
+//             order IS zlib's hash chain (head/prev), walked backwards
+//   match     one lane per position: what longest_match() returns over the first 4096 / 1024
+//             chain entries (max_chain, and max_chain>>2 once prev_length >= good_match), with the
+//             NIL / MAX_DIST / lookahead rules of deflate.c
+//   parse     deflate_slow's lazy evaluation as a walk over "decision positions": per position the
+//             deferral chain is resolved locally, 64-position blocks are summarised by pointer
+//             doubling (entry -> exit, symbol count), one lane per slice hops block to block
+//   symbols   visited positions emit literals / (length, distance) pairs in stream order
+//   trees     per 16383-symbol block: histograms, then build_tree / gen_bitlen / gen_codes /
+//             scan_tree / build_bl_tree exactly as trees.c, stored / static / dynamic choice
+//   emit      code bits of every symbol at its prefix-summed bit offset; zlib header, Adler-32
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <algorithm>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include "cct_internal.h"
+#include "../../include/compact_hip.h"
+
+namespace cct {
+namespace {
+
+constexpr int MIN_MATCH = 3, MAX_MATCH = 258, WSIZE = 32768;
+constexpr int MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1;
+constexpr int MAX_DIST = WSIZE - MIN_LOOKAHEAD;  // 32506
+constexpr int TOO_FAR = 4096;
+constexpr int BLOCK_SYMS = 16383;                // lit_bufsize - 1 (memLevel 8)
+constexpr int L_CODES = 286, D_CODES = 30, BL_CODES = 19, HEAP_SIZE = 2 * L_CODES + 1;
+constexpr int END_BLOCK = 256, MAX_BITS = 15, MAX_BL_BITS = 7;
+
+__constant__ uint8_t c_extra_lbits[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+__constant__ uint8_t c_extra_dbits[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+__constant__ uint8_t c_extra_blbits[19] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,3,7};
+__constant__ uint8_t c_bl_order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+// tr_static_init tables, filled by the host once (cct::deflate_init_tables)
+__constant__ uint8_t c_length_code[256];
+__constant__ uint16_t c_base_length[29];
+__constant__ uint8_t c_dist_code[512];
+__constant__ uint16_t c_base_dist[30];
+__constant__ uint16_t c_static_lcode[288];
+__constant__ uint8_t c_static_llen[288];
+__constant__ uint16_t c_static_dcode[30];
+
+__device__ __forceinline__ int d_code(uint32_t dist) { return dist < 256 ? c_dist_code[dist] : c_dist_code[256 + (dist >> 7)]; }
+
+struct MatchRec { uint16_t len4096, len1024, dist4096, dist1024; };
+
+// ------------------------------------------------------------------ 1. hash + segment bounds
+__global__ void dfl_hash_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const size_t base = (size_t)s * a.in_stride;
+	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		a.seg_begin[s] = (uint32_t)base;
+		a.seg_end[s] = (uint32_t)(base + npos);
+	}
+	for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npos; p += gridDim.x * blockDim.x) {
+		const uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFFu;
+		a.keys_in[base + p] = (uint16_t)h;
+		a.vals_in[base + p] = p;
+	}
+}
+
+// ------------------------------------------------------------------ 2. longest_match for every position
+// lane = sorted index i; its chain = sorted entries i-1, i-2, ... of the same hash (deflate.c:1236-1386)
+__global__ void dfl_match_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const size_t base = (size_t)s * a.in_stride;
+	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
+	const uint16_t *keys = a.keys_out + base;
+	const uint32_t *vals = a.vals_out + base;
+	MatchRec *mr = reinterpret_cast<MatchRec *>(a.mr) + base;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npos; i += gridDim.x * blockDim.x) {
+		const uint32_t p = vals[i];
+		const uint32_t h = keys[i];
+		const uint32_t lookahead = L - p;
+		const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
+		// slide_hash NIL quirk at the very end of the input (see oracle/deflate_model.c)
+		const uint32_t nil_q = (lookahead < (uint32_t)MIN_LOOKAHEAD && p >= 32506u + 32768u && (p - 32506u) % 32768u == 0)
+		                           ? p - 32506u : 0xFFFFFFFFu;
+		int best = 0, count = 0;
+		uint32_t best_q = 0;
+		int len1024 = -1; uint32_t q1024 = 0;
+		const uint8_t *sp = in + p;
+		for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
+			const uint32_t q = vals[j];
+			const uint32_t dist = p - q;
+			if (q == 0 || q == nil_q) break;                         // NIL ends the chain
+			if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
+			const uint8_t *mp = in + q;
+			if (best < max_len && mp[best] == sp[best]) {           // only a longer match can replace the best
+				int len = 0;
+				while (len < max_len && mp[len] == sp[len]) len++;
+				if (len > best) { best = len; best_q = q; }
+			}
+			count++;
+			if (count == 1024) { len1024 = best; q1024 = best_q; }
+			if (best >= max_len) break;                              // len >= nice_match
+			if (count == 4096) break;                                // max_chain_length
+		}
+		if (len1024 < 0) { len1024 = best; q1024 = best_q; }
+		MatchRec r;
+		r.len4096 = (uint16_t)best; r.dist4096 = (uint16_t)(best ? p - best_q : 0);
+		r.len1024 = (uint16_t)len1024; r.dist1024 = (uint16_t)(len1024 ? p - q1024 : 0);
+		mr[p] = r;
+	}
+}
+
+// ------------------------------------------------------------------ 3a. decision records + block summaries
+// rec32: bits 0..7 k (deferred literals), 8..16 match length (0 = none), 17..31 distance
+__device__ __forceinline__ void match_at(const MatchRec *mr, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
+{
+	// deflate_slow: match_length after longest_match + TOO_FAR rule, given prev_length (deflate.c:1863-1880)
+	len = 2; dist = 0;
+	if (p >= npos || prev_len >= MAX_MATCH) return;
+	const MatchRec r = mr[p];
+	const int l = prev_len >= 32 ? r.len1024 : r.len4096;
+	const int d = prev_len >= 32 ? r.dist1024 : r.dist4096;
+	if (l > prev_len && l >= MIN_MATCH) { len = l; dist = d; }
+	if (len == MIN_MATCH && dist > TOO_FAR) len = 2;
+}
+
+__global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const size_t base = (size_t)s * a.in_stride;
+	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
+	const MatchRec *mr = reinterpret_cast<const MatchRec *>(a.mr) + base;
+	const uint32_t nblk64 = (L + 63) / 64;
+	const int lane = threadIdx.x & 63;
+	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
+		const uint32_t p = wb * 64 + lane;
+		const uint32_t blk_end = wb * 64 + 64;
+		uint32_t rec = 0, nxt = blk_end, cnt = 0;
+		if (p < L) {
+			int len, dist;
+			match_at(mr, p, npos, 2, len, dist);
+			if (len < MIN_MATCH) { rec = 0; nxt = p + 1; cnt = 1; }  // literal in[p]
+			else {
+				uint32_t k = 0;
+				for (;;) {  // lazy evaluation: defer while the next position has a longer match
+					int l2, d2;
+					match_at(mr, p + k + 1, npos, len, l2, d2);
+					if (l2 > len) { len = l2; dist = d2; k++; } else break;
+				}
+				rec = k | ((uint32_t)len << 8) | ((uint32_t)dist << 17);
+				nxt = p + k + (uint32_t)len;
+				cnt = k + 1;
+			}
+		}
+		a.rec32[base + p] = rec;  // in_stride >= L rounded up to 256, so p < stride
+		// entry -> exit summary of this 64-position block by pointer doubling
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			const bool inside = nxt < blk_end;
+			const int j = inside ? (int)(nxt - wb * 64) : lane;
+			const uint32_t n2 = __shfl(nxt, j), c2 = __shfl(cnt, j);
+			if (inside) { nxt = n2; cnt += c2; }
+		}
+		a.exit_pos[base + p] = nxt;
+		a.exit_cnt[base + p] = cnt;
+	}
+}
+
+// ------------------------------------------------------------------ 3b. block-to-block walk (one lane per slice)
+__global__ void dfl_walk_kernel(DeflateArgs a, int n)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const uint32_t L = a.in_sizes[s];
+	const size_t base = (size_t)s * a.in_stride;
+	const size_t bbase = (size_t)s * (a.in_stride / 64);
+	uint32_t cur = 0, syms = 0;
+	while (cur < L) {
+		const uint32_t b = cur >> 6;
+		a.blk_entry[bbase + b] = cur;
+		a.blk_symbase[bbase + b] = syms;
+		syms += a.exit_cnt[base + cur];
+		cur = a.exit_pos[base + cur];
+	}
+	a.total_syms[s] = syms;
+}
+
+// ------------------------------------------------------------------ 3c. symbols in stream order
+// sym32: bits 0..7 lc (literal or length-3), bits 16..31 distance (0 = literal)
+__global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const size_t base = (size_t)s * a.in_stride;
+	const size_t bbase = (size_t)s * (a.in_stride / 64);
+	const uint32_t nblk64 = (L + 63) / 64;
+	const int lane = threadIdx.x & 63;
+	uint32_t *sym = a.sym + base;
+	uint32_t *bend = a.blk_end + (size_t)s * a.max_blocks;
+	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
+		const uint32_t entry = a.blk_entry[bbase + wb];
+		if (entry == 0xFFFFFFFFu) continue;  // block jumped over by a match
+		const uint32_t p = wb * 64 + lane;
+		const uint32_t rec = (p < L) ? a.rec32[base + p] : 0;
+		const uint32_t k = rec & 0xFFu, len = (rec >> 8) & 0x1FFu, dist = rec >> 17;
+		const uint32_t nxt = len ? p + k + len : p + 1;
+		const uint32_t cnt = len ? k + 1 : 1;
+		// which lanes are decision positions: follow next from the entry (wave-uniform loop)
+		uint64_t visited = 0;
+		uint32_t cur = entry;
+		while (cur < wb * 64 + 64 && cur < L) {
+			const int j = __builtin_amdgcn_readfirstlane((int)(cur - wb * 64));
+			visited |= 1ull << j;
+			cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt, j);
+		}
+		const bool mine = (visited >> lane) & 1ull;
+		// exclusive prefix of symbol counts over the visited lanes
+		uint32_t v = mine ? cnt : 0u, inc = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d);
+			if (lane >= d) inc += t;
+		}
+		uint32_t off = a.blk_symbase[bbase + wb] + inc - v;
+		if (mine) {
+			if (p == L - 1) a.postloop_lit[s] = 1;  // the literal tallied after deflate_slow's main loop
+			for (uint32_t t = 0; t < (len ? k : 1u); t++, off++) {  // literals
+				sym[off] = in[p + t];
+				if (off % BLOCK_SYMS == BLOCK_SYMS - 1) bend[off / BLOCK_SYMS] = p + t + 1;
+			}
+			if (len) {
+				sym[off] = (len - MIN_MATCH) | (dist << 16);
+				if (off % BLOCK_SYMS == BLOCK_SYMS - 1) bend[off / BLOCK_SYMS] = p + k + len;
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------ 4. Huffman trees per block (trees.c)
+struct TreeScratch {  // one block's working set, in LDS
+	uint16_t freq[HEAP_SIZE], dad[HEAP_SIZE], len[HEAP_SIZE], code[HEAP_SIZE];        // literal/length tree
+	uint16_t dfreq[2 * D_CODES + 1], ddad[2 * D_CODES + 1], dlen[2 * D_CODES + 1], dcode[2 * D_CODES + 1];
+	uint16_t bfreq[2 * BL_CODES + 1], bdad[2 * BL_CODES + 1], blen[2 * BL_CODES + 1], bcode[2 * BL_CODES + 1];
+	uint16_t heap[HEAP_SIZE];
+	uint8_t depth[HEAP_SIZE];
+	uint16_t bl_count[MAX_BITS + 1];
+	int heap_len, heap_max;
+	uint32_t opt_len, static_len;
+	uint32_t hdr_bits[160];  // dynamic-block header: 14 + 3*19 + up to 316 * 14 bits
+	uint32_t hdr_nbits;
+};
+
+struct TreeView { uint16_t *freq, *dad, *len, *code; };
+
+__device__ __forceinline__ bool smaller(const TreeView &t, const uint8_t *depth, int n, int m)
+{
+	return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && depth[n] <= depth[m]);
+}
+
+__device__ void pqdownheap(TreeScratch &S, const TreeView &t, int k)
+{
+	const int v = S.heap[k];
+	int j = k << 1;
+	while (j <= S.heap_len) {
+		if (j < S.heap_len && smaller(t, S.depth, S.heap[j + 1], S.heap[j])) j++;
+		if (smaller(t, S.depth, v, S.heap[j])) break;
+		S.heap[k] = S.heap[j];
+		k = j;
+		j <<= 1;
+	}
+	S.heap[k] = (uint16_t)v;
+}
+
+__device__ uint32_t bi_reverse(uint32_t code, int len)
+{
+	uint32_t res = 0;
+	do { res |= code & 1; code >>= 1; res <<= 1; } while (--len > 0);
+	return res >> 1;
+}
+
+// build_tree + gen_bitlen + gen_codes (trees.c:486-700).  kind: 0 literal/length, 1 distance, 2 bit-length
+__device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
+{
+	const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
+	const int max_length = kind == 2 ? MAX_BL_BITS : MAX_BITS;
+	const int base = kind == 0 ? 257 : 0;
+	int n, m, max_code = -1, node;
+	S.heap_len = 0; S.heap_max = HEAP_SIZE;
+	for (n = 0; n < elems; n++) {
+		if (t.freq[n] != 0) { S.heap[++S.heap_len] = (uint16_t)(max_code = n); S.depth[n] = 0; }
+		else t.len[n] = 0;
+	}
+	while (S.heap_len < 2) {
+		node = S.heap[++S.heap_len] = (uint16_t)(max_code < 2 ? ++max_code : 0);
+		t.freq[node] = 1; S.depth[node] = 0; S.opt_len--;
+		if (kind == 0) S.static_len -= c_static_llen[node];
+		else if (kind == 1) S.static_len -= 5;
+	}
+	for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, t, n);
+	node = elems;
+	do {
+		n = S.heap[1]; S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, t, 1);
+		m = S.heap[1];
+		S.heap[--S.heap_max] = (uint16_t)n; S.heap[--S.heap_max] = (uint16_t)m;
+		t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
+		S.depth[node] = (uint8_t)((S.depth[n] >= S.depth[m] ? S.depth[n] : S.depth[m]) + 1);
+		t.dad[n] = t.dad[m] = (uint16_t)node;
+		S.heap[1] = (uint16_t)node++;
+		pqdownheap(S, t, 1);
+	} while (S.heap_len >= 2);
+	S.heap[--S.heap_max] = S.heap[1];
+	// gen_bitlen
+	int h, bits, overflow = 0;
+	for (bits = 0; bits <= MAX_BITS; bits++) S.bl_count[bits] = 0;
+	t.len[S.heap[S.heap_max]] = 0;
+	for (h = S.heap_max + 1; h < HEAP_SIZE; h++) {
+		n = S.heap[h];
+		bits = t.len[t.dad[n]] + 1;
+		if (bits > max_length) { bits = max_length; overflow++; }
+		t.len[n] = (uint16_t)bits;
+		if (n > max_code) continue;
+		S.bl_count[bits]++;
+		int xbits = 0;
+		if (n >= base) xbits = kind == 0 ? c_extra_lbits[n - base] : kind == 1 ? c_extra_dbits[n] : c_extra_blbits[n];
+		const uint32_t f = t.freq[n];
+		S.opt_len += f * (uint32_t)(bits + xbits);
+		if (kind == 0) S.static_len += f * (uint32_t)(c_static_llen[n] + xbits);
+		else if (kind == 1) S.static_len += f * (uint32_t)(5 + xbits);
+	}
+	if (overflow > 0) {
+		do {
+			bits = max_length - 1;
+			while (S.bl_count[bits] == 0) bits--;
+			S.bl_count[bits]--; S.bl_count[bits + 1] += 2; S.bl_count[max_length]--;
+			overflow -= 2;
+		} while (overflow > 0);
+		for (bits = max_length; bits != 0; bits--) {
+			n = S.bl_count[bits];
+			while (n != 0) {
+				m = S.heap[--h];
+				if (m > max_code) continue;
+				if ((uint32_t)t.len[m] != (uint32_t)bits) {
+					S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
+					t.len[m] = (uint16_t)bits;
+				}
+				n--;
+			}
+		}
+	}
+	// gen_codes
+	uint16_t next_code[MAX_BITS + 1];
+	uint32_t code = 0;
+	for (bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
+	for (n = 0; n <= max_code; n++) {
+		const int len = t.len[n];
+		if (len == 0) continue;
+		t.code[n] = (uint16_t)bi_reverse(next_code[len]++, len);
+	}
+	return max_code;
+}
+
+__device__ void scan_tree(TreeScratch &S, const TreeView &t, int max_code)
+{
+	int n, prevlen = -1, curlen, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
+	if (nextlen == 0) { max_count = 138; min_count = 3; }
+	t.len[max_code + 1] = 0xffff;
+	for (n = 0; n <= max_code; n++) {
+		curlen = nextlen; nextlen = t.len[n + 1];
+		if (++count < max_count && curlen == nextlen) continue;
+		else if (count < min_count) S.bfreq[curlen] += (uint16_t)count;
+		else if (curlen != 0) { if (curlen != prevlen) S.bfreq[curlen]++; S.bfreq[16]++; }
+		else if (count <= 10) S.bfreq[17]++;
+		else S.bfreq[18]++;
+		count = 0; prevlen = curlen;
+		if (nextlen == 0) { max_count = 138; min_count = 3; }
+		else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+		else { max_count = 7; min_count = 4; }
+	}
+}
+
+__device__ __forceinline__ void hdr_put(TreeScratch &S, uint32_t value, int length)
+{
+	const uint32_t pos = S.hdr_nbits;
+	const uint32_t w = pos >> 5, sh = pos & 31;
+	S.hdr_bits[w] |= value << sh;
+	if (sh + length > 32) S.hdr_bits[w + 1] |= value >> (32 - sh);
+	S.hdr_nbits = pos + length;
+}
+
+__device__ void send_tree(TreeScratch &S, const TreeView &t, int max_code)
+{
+	int n, prevlen = -1, curlen, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
+	if (nextlen == 0) { max_count = 138; min_count = 3; }
+	for (n = 0; n <= max_code; n++) {
+		curlen = nextlen; nextlen = t.len[n + 1];
+		if (++count < max_count && curlen == nextlen) continue;
+		else if (count < min_count) { do { hdr_put(S, S.bcode[curlen], S.blen[curlen]); } while (--count != 0); }
+		else if (curlen != 0) {
+			if (curlen != prevlen) { hdr_put(S, S.bcode[curlen], S.blen[curlen]); count--; }
+			hdr_put(S, S.bcode[16], S.blen[16]); hdr_put(S, (uint32_t)(count - 3), 2);
+		} else if (count <= 10) { hdr_put(S, S.bcode[17], S.blen[17]); hdr_put(S, (uint32_t)(count - 3), 3); }
+		else { hdr_put(S, S.bcode[18], S.blen[18]); hdr_put(S, (uint32_t)(count - 11), 7); }
+		count = 0; prevlen = curlen;
+		if (nextlen == 0) { max_count = 138; min_count = 3; }
+		else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+		else { max_count = 7; min_count = 4; }
+	}
+}
+
+// one workgroup per (slice, block): histogram by all lanes, trees by lane 0 (trees.c _tr_flush_block)
+__global__ void __launch_bounds__(256) dfl_tree_kernel(DeflateArgs a)
+{
+	__shared__ TreeScratch S;
+	const int s = blockIdx.y, m = blockIdx.x;
+	const uint32_t T = a.total_syms[s];
+	const uint32_t L = a.in_sizes[s];
+	// number of blocks: one flush per 16383 tallied symbols inside the loop, plus the final flush
+	uint32_t nfull = T / BLOCK_SYMS;
+	if (T % BLOCK_SYMS == 0 && nfull > 0 && a.postloop_lit[s]) nfull--;  // the post-loop literal never flushes
+	const uint32_t nblocks = nfull + 1;
+	BlockMeta *meta = a.block_meta + (size_t)s * a.max_blocks;
+	if ((uint32_t)m >= nblocks) return;
+	const bool last = (uint32_t)m == nblocks - 1;
+	const uint32_t first = (uint32_t)m * BLOCK_SYMS;
+	const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
+	const uint32_t *sym = a.sym + (size_t)s * a.in_stride + first;
+	const uint32_t *bend = a.blk_end + (size_t)s * a.max_blocks;
+	const uint32_t in_begin = m == 0 ? 0u : bend[m - 1];
+	const uint32_t in_end = last ? L : bend[m];
+
+	for (int i = threadIdx.x; i < HEAP_SIZE; i += blockDim.x) { S.freq[i] = 0; S.len[i] = 0; S.dad[i] = 0; S.code[i] = 0; }
+	for (int i = threadIdx.x; i < 2 * D_CODES + 1; i += blockDim.x) { S.dfreq[i] = 0; S.dlen[i] = 0; S.ddad[i] = 0; S.dcode[i] = 0; }
+	for (int i = threadIdx.x; i < 2 * BL_CODES + 1; i += blockDim.x) { S.bfreq[i] = 0; S.blen[i] = 0; S.bdad[i] = 0; S.bcode[i] = 0; }
+	for (int i = threadIdx.x; i < 160; i += blockDim.x) S.hdr_bits[i] = 0;
+	__shared__ uint32_t hl[L_CODES], hd[D_CODES];
+	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) hl[i] = 0;
+	if (threadIdx.x < D_CODES) hd[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < nsym; i += blockDim.x) {
+		const uint32_t v = sym[i];
+		const uint32_t dist = v >> 16, lc = v & 0xFFu;
+		if (dist == 0) atomicAdd(&hl[lc], 1u);
+		else { atomicAdd(&hl[c_length_code[lc] + 256 + 1], 1u); atomicAdd(&hd[d_code(dist - 1)], 1u); }
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) S.freq[i] = (uint16_t)hl[i];
+	if (threadIdx.x < D_CODES) S.dfreq[threadIdx.x] = (uint16_t)hd[threadIdx.x];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		S.freq[END_BLOCK] = 1;
+		S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0;
+		const TreeView lt{S.freq, S.dad, S.len, S.code}, dt{S.dfreq, S.ddad, S.dlen, S.dcode}, bt{S.bfreq, S.bdad, S.blen, S.bcode};
+		const int lmax = build_tree(S, lt, 0);
+		const int dmax = build_tree(S, dt, 1);
+		const uint32_t dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
+		scan_tree(S, lt, lmax);
+		scan_tree(S, dt, dmax);
+		build_tree(S, bt, 2);
+		int max_blindex;
+		for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
+			if (S.blen[c_bl_order[max_blindex]] != 0) break;
+		S.opt_len += 3 * ((uint32_t)max_blindex + 1) + 5 + 5 + 4;
+		uint32_t opt_lenb = (S.opt_len + 3 + 7) >> 3;
+		const uint32_t static_lenb = (S.static_len + 3 + 7) >> 3;
+		if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+		const uint32_t stored_len = in_end - in_begin;
+		// stored blocks need block_start >= 0 in window coordinates; a block that an incompressible
+		// verdict could apply to spans < 32 KiB of input, so its start is always inside the window
+		BlockMeta bm;
+		bm.in_begin = in_begin; bm.stored_len = stored_len; bm.first_sym = first; bm.nsym = nsym; bm.last = last ? 1u : 0u;
+		if (stored_len + 4 <= opt_lenb) {
+			bm.type = 0; bm.hdr_nbits = 0; bm.body_bits = 0;
+		} else if (static_lenb == opt_lenb) {
+			bm.type = 1; bm.hdr_nbits = 0; bm.body_bits = S.static_len;
+		} else {
+			bm.type = 2;
+			hdr_put(S, (uint32_t)(lmax + 1 - 257), 5);
+			hdr_put(S, (uint32_t)(dmax + 1 - 1), 5);
+			hdr_put(S, (uint32_t)(max_blindex + 1 - 4), 4);
+			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[c_bl_order[rank]], 3);
+			send_tree(S, lt, lmax);
+			send_tree(S, dt, dmax);
+			bm.hdr_nbits = S.hdr_nbits;
+			bm.body_bits = dyn_body_bits;
+		}
+		meta[m] = bm;
+		if (m == 0) a.n_blocks[s] = nblocks;
+	}
+	__syncthreads();
+	// publish code tables and header bits for the emit kernel
+	BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m);
+	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) { bt->lcode[i] = S.code[i]; bt->llen[i] = (uint8_t)S.len[i]; }
+	if (threadIdx.x < D_CODES) { bt->dcode[threadIdx.x] = S.dcode[threadIdx.x]; bt->dlen[threadIdx.x] = (uint8_t)S.dlen[threadIdx.x]; }
+	for (int i = threadIdx.x; i < 160; i += blockDim.x) bt->hdr_bits[i] = S.hdr_bits[i];
+}
+
+// ------------------------------------------------------------------ 5. Adler-32 + layout
+__global__ void __launch_bounds__(256) dfl_adler_kernel(DeflateArgs a)
+{
+	__shared__ unsigned long long sa[256], sb[256];
+	const int s = blockIdx.x;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	unsigned long long A = 0, B = 0;
+	for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) {
+		const unsigned long long d = in[i];
+		A += d;
+		B += (unsigned long long)(L - i) * d;
+	}
+	sa[threadIdx.x] = A; sb[threadIdx.x] = B;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if ((int)threadIdx.x < st) { sa[threadIdx.x] += sa[threadIdx.x + st]; sb[threadIdx.x] += sb[threadIdx.x + st]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const uint32_t lo = (uint32_t)((1ull + sa[0]) % 65521ull);
+		const uint32_t hi = (uint32_t)(((unsigned long long)L + sb[0]) % 65521ull);
+		a.adler[s] = (hi << 16) | lo;
+	}
+}
+
+// bit offsets of every block, .cct header, zlib header, Adler trailer, final size (one lane per slice)
+__global__ void dfl_layout_kernel(DeflateArgs a, int n)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	uint8_t *out = a.out + (size_t)s * a.out_stride;
+	for (int i = 0; i < 13; i++) out[i] = a.header13[i];
+	out[13] = 0x78; out[14] = 0xDA;  // CMF/FLG for wbits 15, level 9 (deflate.c:819-836)
+	uint64_t bit = 8ull * 15;
+	BlockMeta *meta = a.block_meta + (size_t)s * a.max_blocks;
+	const uint32_t nb = a.n_blocks[s];
+	for (uint32_t m = 0; m < nb; m++) {
+		BlockMeta bm = meta[m];
+		bm.bit_off = bit;
+		if (bm.type == 0) {  // _tr_stored_block: 3 header bits, bi_windup, LEN, NLEN, bytes
+			bit = (bit + 3 + 7) & ~7ull;
+			bit += 32 + 8ull * bm.stored_len;
+		} else {
+			bit += 3 + bm.hdr_nbits + bm.body_bits;
+		}
+		if (bm.last) bit = (bit + 7) & ~7ull;  // bi_windup
+		meta[m] = bm;
+	}
+	const uint64_t byte = bit >> 3;
+	const uint32_t ad = a.adler[s];
+	out[byte + 0] = (uint8_t)(ad >> 24); out[byte + 1] = (uint8_t)(ad >> 16);
+	out[byte + 2] = (uint8_t)(ad >> 8);  out[byte + 3] = (uint8_t)ad;
+	a.out_sizes[s] = (uint32_t)(byte + 4);
+}
+
+// ------------------------------------------------------------------ 6. bit emission
+__device__ __forceinline__ void or_bits(uint32_t *words, uint64_t bit, uint64_t value, int nbits)
+{
+	// value has nbits <= 48 significant bits; LSB-first packing (send_bits, trees.c:187-228)
+	if (nbits == 0) return;
+	const uint64_t w = bit >> 5;
+	const int sh = (int)(bit & 31);
+	const uint64_t lo = value << sh;                       // bits 0..63 of value << sh
+	const uint64_t hi = sh ? (value >> (64 - sh)) : 0ull;  // bits 64.. (nbits <= 48, sh <= 31)
+	atomicOr(&words[w], (uint32_t)lo);
+	if (sh + nbits > 32) atomicOr(&words[w + 1], (uint32_t)(lo >> 32));
+	if (sh + nbits > 64) atomicOr(&words[w + 2], (uint32_t)hi);
+}
+
+__global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
+{
+	__shared__ uint32_t wsum[4];
+	__shared__ unsigned long long s_run;
+	const int s = blockIdx.y, m = blockIdx.x;
+	if ((uint32_t)m >= a.n_blocks[s]) return;
+	const BlockMeta bm = a.block_meta[(size_t)s * a.max_blocks + m];
+	const BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m);
+	uint8_t *out = a.out + (size_t)s * a.out_stride;
+	uint32_t *words = reinterpret_cast<uint32_t *>(out);
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	uint64_t bit = bm.bit_off;
+	if (bm.type == 0) {
+		if (threadIdx.x == 0) or_bits(words, bit, (uint64_t)bm.last, 3);
+		const uint64_t byte = ((bit + 3 + 7) & ~7ull) >> 3;
+		if (threadIdx.x == 0) {
+			out[byte] = (uint8_t)(bm.stored_len & 0xFF); out[byte + 1] = (uint8_t)(bm.stored_len >> 8);
+			out[byte + 2] = (uint8_t)(~bm.stored_len & 0xFF); out[byte + 3] = (uint8_t)((~bm.stored_len >> 8) & 0xFF);
+		}
+		for (uint32_t i = threadIdx.x; i < bm.stored_len; i += blockDim.x) out[byte + 4 + i] = in[bm.in_begin + i];
+		return;
+	}
+	if (threadIdx.x == 0) or_bits(words, bit, (uint64_t)((bm.type << 1) + bm.last), 3);
+	bit += 3;
+	if (bm.type == 2) {
+		for (uint32_t i = threadIdx.x; i * 32 < bm.hdr_nbits; i += blockDim.x) {
+			const int nb = (int)min(32u, bm.hdr_nbits - i * 32);
+			or_bits(words, bit + 32ull * i, bt->hdr_bits[i], nb);
+		}
+		bit += bm.hdr_nbits;
+	}
+	const uint32_t *sym = a.sym + (size_t)s * a.in_stride + bm.first_sym;
+	const bool dyn = bm.type == 2;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_run = bit;
+	__syncthreads();
+	for (uint32_t base = 0; base <= bm.nsym; base += blockDim.x) {  // one extra slot for END_BLOCK
+		const uint32_t i = base + threadIdx.x;
+		uint64_t bits = 0;
+		int nb = 0;
+		if (i < bm.nsym) {
+			const uint32_t v = sym[i];
+			uint32_t dist = v >> 16;
+			const uint32_t lc = v & 0xFFu;
+			if (dist == 0) {
+				bits = dyn ? bt->lcode[lc] : c_static_lcode[lc];
+				nb = dyn ? bt->llen[lc] : c_static_llen[lc];
+			} else {  // compress_block, trees.c:1070-1110
+				int code = c_length_code[lc];
+				const int lsym = code + 256 + 1;
+				bits = dyn ? bt->lcode[lsym] : c_static_lcode[lsym];
+				nb = dyn ? bt->llen[lsym] : c_static_llen[lsym];
+				int extra = c_extra_lbits[code];
+				if (extra) { bits |= (uint64_t)(lc - c_base_length[code]) << nb; nb += extra; }
+				dist--;
+				code = d_code(dist);
+				bits |= (uint64_t)(dyn ? bt->dcode[code] : c_static_dcode[code]) << nb;
+				nb += dyn ? bt->dlen[code] : 5;
+				extra = c_extra_dbits[code];
+				if (extra) { bits |= (uint64_t)(dist - c_base_dist[code]) << nb; nb += extra; }
+			}
+		} else if (i == bm.nsym) {
+			bits = dyn ? bt->lcode[END_BLOCK] : c_static_lcode[END_BLOCK];
+			nb = dyn ? bt->llen[END_BLOCK] : c_static_llen[END_BLOCK];
+		}
+		// exclusive scan of bit counts over the workgroup
+		uint32_t inc = (uint32_t)nb;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d);
+			if (lane >= d) inc += t;
+		}
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t wb = 0, tot = 0;
+		for (int w = 0; w < 4; w++) { if (w < wave) wb += wsum[w]; tot += wsum[w]; }
+		const uint64_t run = s_run;
+		or_bits(words, run + wb + inc - (uint32_t)nb, bits, nb);
+		__syncthreads();
+		if (threadIdx.x == 0) s_run = run + tot;
+		__syncthreads();
+	}
+}
+
+__global__ void dfl_offsets_kernel(DeflateArgs a, int n)
+{
+	// blk_entry := "not entered", postloop flags, for the walk kernel
+	const size_t per = a.in_stride / 64;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x)
+		a.blk_entry[i] = 0xFFFFFFFFu;
+	if (blockIdx.x == 0)
+		for (int s = threadIdx.x; s < n; s += blockDim.x) a.postloop_lit[s] = 0;
+}
+
+}  // namespace
+
+// host: trees.c tr_static_init tables -> constant memory
+hipError_t deflate_init_tables()
+{
+	uint8_t length_code[256]; uint16_t base_length[29]; uint8_t dist_code[512]; uint16_t base_dist[30];
+	uint16_t static_lcode[288]; uint8_t static_llen[288]; uint16_t static_dcode[30];
+	static const int xl[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+	static const int xd[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+	int length = 0, code, n, dist = 0;
+	for (code = 0; code < 28; code++) {
+		base_length[code] = (uint16_t)length;
+		for (n = 0; n < (1 << xl[code]); n++) length_code[length++] = (uint8_t)code;
+	}
+	length_code[length - 1] = (uint8_t)code;
+	base_length[28] = 0;
+	for (code = 0; code < 16; code++) {
+		base_dist[code] = (uint16_t)dist;
+		for (n = 0; n < (1 << xd[code]); n++) dist_code[dist++] = (uint8_t)code;
+	}
+	dist >>= 7;
+	for (; code < 30; code++) {
+		base_dist[code] = (uint16_t)(dist << 7);
+		for (n = 0; n < (1 << (xd[code] - 7)); n++) dist_code[256 + dist++] = (uint8_t)code;
+	}
+	uint16_t bl_count[16] = {0}, next_code[16];
+	n = 0;
+	while (n <= 143) { static_llen[n++] = 8; bl_count[8]++; }
+	while (n <= 255) { static_llen[n++] = 9; bl_count[9]++; }
+	while (n <= 279) { static_llen[n++] = 7; bl_count[7]++; }
+	while (n <= 287) { static_llen[n++] = 8; bl_count[8]++; }
+	unsigned c = 0;
+	for (int bits = 1; bits <= 15; bits++) { c = (c + bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)c; }
+	auto rev = [](unsigned v, int len) { unsigned r = 0; do { r |= v & 1; v >>= 1; r <<= 1; } while (--len > 0); return r >> 1; };
+	for (n = 0; n < 288; n++) static_lcode[n] = (uint16_t)rev(next_code[static_llen[n]]++, static_llen[n]);
+	for (n = 0; n < 30; n++) static_dcode[n] = (uint16_t)rev((unsigned)n, 5);
+	hipError_t e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_length_code), length_code, sizeof length_code)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_base_length), base_length, sizeof base_length)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_dist_code), dist_code, sizeof dist_code)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_base_dist), base_dist, sizeof base_dist)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_static_lcode), static_lcode, sizeof static_lcode)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_static_llen), static_llen, sizeof static_llen)) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_static_dcode), static_dcode, sizeof static_dcode)) != hipSuccess) return e;
+	return hipSuccess;
+}
+
+size_t deflate_sort_temp_bytes(size_t total, int n)
+{
+	size_t bytes = 0;
+	(void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (uint16_t *)nullptr, (uint16_t *)nullptr, (uint32_t *)nullptr,
+	                                          (uint32_t *)nullptr, (unsigned int)total, (unsigned int)n, (uint32_t *)nullptr,
+	                                          (uint32_t *)nullptr, 0, 15, (hipStream_t)0);
+	return bytes;
+}
+
+hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st)
+{
+	const size_t total = (size_t)n * a.in_stride;
+	hipError_t e;
+	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(256), dim3(256), 0, st, a, n);
+	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
+	hipLaunchKernelGGL(dfl_hash_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	size_t tb = sort_temp_bytes;
+	if ((e = rocprim::segmented_radix_sort_pairs(sort_temp, tb, a.keys_in, a.keys_out, a.vals_in, a.vals_out,
+	                                             (unsigned int)total, (unsigned int)n, a.seg_begin, a.seg_end, 0, 15, st)) != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(dfl_match_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_emit_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+}  // namespace cct

@@ -129,6 +129,15 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
                      uint32_t *h_payload_sizes /* may be NULL */,
                      cct_slice_stats *h_stats /* may be NULL */);
 
+/* DEFLATE stage alone, on the device: n byte strings (h_in[h_offsets[i] .. h_offsets[i+1])) ->
+ * n zlib streams byte-identical to zlib 1.2.11 compress2(level 9), i.e. CPython's
+ * zlib.compress(data, level=9) that the reference calls at core.py:340.  Stream i lands at
+ * h_out + i*out_stride; out_stride >= compressBound(longest input rounded up to 256) + 64.
+ * Option "device_deflate" (default 1) selects this implementation inside cct_encode_batch;
+ * 0 runs libz on the host thread team instead. */
+int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n,
+                            uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes);
+
 /* ---- decode ----------------------------------------------------------------------- */
 /* Replaces Decoder.read_header (core.py:385-402). */
 int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_header *out);
