@@ -316,12 +316,12 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	if ((rc = g_ctx.z_vals_out.ensure(E * 4))) return rc;
 	if ((rc = g_ctx.z_mr.ensure(E * 8))) return rc;
 	if ((rc = g_ctx.z_rec.ensure(E * 4))) return rc;
+	if ((rc = g_ctx.z_sym.ensure(E * 4))) return rc;
 	if ((rc = g_ctx.z_exitp.ensure(E * 4))) return rc;
 	if ((rc = g_ctx.z_exitc.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_sym.ensure(E * 4))) return rc;
 	if ((rc = g_ctx.z_bentry.ensure(E / 64 * 4))) return rc;
 	if ((rc = g_ctx.z_bsym.ensure(E / 64 * 4))) return rc;
-	if ((rc = g_ctx.z_small.ensure((size_t)n * 6 * 4))) return rc;
+	if ((rc = g_ctx.z_small.ensure((size_t)n * 9 * 4))) return rc;
 	if ((rc = g_ctx.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
 	if ((rc = g_ctx.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
 	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
@@ -335,9 +335,10 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.vals_in = (uint32_t *)g_ctx.z_vals_in.p; a.vals_out = (uint32_t *)g_ctx.z_vals_out.p;
 	uint32_t *small = (uint32_t *)g_ctx.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
-	a.n_blocks = small + 4 * n; a.adler = small + 5 * n;
-	a.mr = g_ctx.z_mr.p; a.rec32 = (uint32_t *)g_ctx.z_rec.p;
-	a.exit_pos = (uint32_t *)g_ctx.z_exitp.p; a.exit_cnt = (uint32_t *)g_ctx.z_exitc.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
+	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n;
+	a.mr = g_ctx.z_mr.p; a.heavy_list = (uint32_t *)g_ctx.z_rec.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
+	a.run_ends = (uint32_t *)g_ctx.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
+	a.rec32 = (uint32_t *)g_ctx.z_exitp.p; a.exit_pos = (uint32_t *)g_ctx.z_exitc.p; a.exit_cnt = (uint32_t *)g_ctx.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
 	a.blk_entry = (uint32_t *)g_ctx.z_bentry.p; a.blk_symbase = (uint32_t *)g_ctx.z_bsym.p;
 	a.blk_end = (uint32_t *)g_ctx.z_bend.p;
 	a.block_meta = (BlockMeta *)g_ctx.z_meta.p; a.block_tables = (BlockTables *)g_ctx.z_tables.p;

@@ -86,9 +86,10 @@ struct DeflateArgs {
 	uint16_t *keys_in, *keys_out; uint32_t *vals_in, *vals_out;      // n * in_stride each
 	uint32_t *seg_begin, *seg_end;                                   // n
 	void *mr;                                                        // n * in_stride * 8 bytes
-	uint32_t *rec32, *exit_pos, *exit_cnt, *sym;                     // n * in_stride each
+	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each
+	uint32_t *rec32, *exit_pos, *exit_cnt;                           // n * in_stride each
 	uint32_t *blk_entry, *blk_symbase;                               // n * in_stride / 64
-	uint32_t *total_syms, *postloop_lit, *n_blocks, *adler;          // n
+	uint32_t *total_syms, *postloop_lit, *n_blocks, *adler, *heavy_count, *deep_count, *run_end_count;  // n
 	uint32_t *blk_end;                                               // n * max_blocks
 	BlockMeta *block_meta; BlockTables *block_tables;                // n * max_blocks
 	int max_blocks;

@@ -73,7 +73,18 @@ __global__ void dfl_hash_kernel(DeflateArgs a)
 }
 
 // ------------------------------------------------------------------ 2. longest_match for every position
-// lane = sorted index i; its chain = sorted entries i-1, i-2, ... of the same hash (deflate.c:1236-1386)
+// The chain of sorted index i = sorted entries i-1, i-2, ... of the same hash (deflate.c:1236-1386).
+// Pass A: one lane per position walks at most LIGHT_STEPS candidates; positions whose chain is
+// longer ("heavy": long runs of one byte put tens of thousands of strings in one bucket) are queued.
+// Pass B: one WAVE per heavy position, 64 candidates per step.
+constexpr int LIGHT_STEPS = 64;
+
+__device__ __forceinline__ uint32_t nil_candidate(uint32_t p, uint32_t lookahead)
+{
+	// slide_hash NIL quirk at the very end of the input (see oracle/deflate_model.c)
+	return (lookahead < (uint32_t)MIN_LOOKAHEAD && p >= 32506u + 32768u && (p - 32506u) % 32768u == 0) ? p - 32506u : 0xFFFFFFFFu;
+}
+
 __global__ void dfl_match_kernel(DeflateArgs a)
 {
 	const int s = blockIdx.y;
@@ -84,19 +95,19 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 	const uint16_t *keys = a.keys_out + base;
 	const uint32_t *vals = a.vals_out + base;
 	MatchRec *mr = reinterpret_cast<MatchRec *>(a.mr) + base;
+	uint32_t *heavy = a.heavy_list + base;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npos; i += gridDim.x * blockDim.x) {
 		const uint32_t p = vals[i];
 		const uint32_t h = keys[i];
 		const uint32_t lookahead = L - p;
 		const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
-		// slide_hash NIL quirk at the very end of the input (see oracle/deflate_model.c)
-		const uint32_t nil_q = (lookahead < (uint32_t)MIN_LOOKAHEAD && p >= 32506u + 32768u && (p - 32506u) % 32768u == 0)
-		                           ? p - 32506u : 0xFFFFFFFFu;
+		const uint32_t nil_q = nil_candidate(p, lookahead);
 		int best = 0, count = 0;
 		uint32_t best_q = 0;
-		int len1024 = -1; uint32_t q1024 = 0;
 		const uint8_t *sp = in + p;
+		bool done = true;
 		for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
+			if (count == LIGHT_STEPS) { done = false; break; }        // heavy: finish cooperatively
 			const uint32_t q = vals[j];
 			const uint32_t dist = p - q;
 			if (q == 0 || q == nil_q) break;                         // NIL ends the chain
@@ -108,15 +119,188 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 				if (len > best) { best = len; best_q = q; }
 			}
 			count++;
-			if (count == 1024) { len1024 = best; q1024 = best_q; }
 			if (best >= max_len) break;                              // len >= nice_match
-			if (count == 4096) break;                                // max_chain_length
 		}
-		if (len1024 < 0) { len1024 = best; q1024 = best_q; }
-		MatchRec r;
-		r.len4096 = (uint16_t)best; r.dist4096 = (uint16_t)(best ? p - best_q : 0);
-		r.len1024 = (uint16_t)len1024; r.dist1024 = (uint16_t)(len1024 ? p - q1024 : 0);
-		mr[p] = r;
+		if (done) {
+			MatchRec r;
+			r.len4096 = r.len1024 = (uint16_t)best;
+			r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
+			mr[p] = r;
+		} else {
+			// sentinel carrying the sorted index.  Deep inside a run of one byte deflate_slow almost never
+			// stops (the run is consumed by one match), so those positions are evaluated only if the parse
+			// really reaches them (dfl_parse_kernel); everything else is queued for the parallel heavy pass.
+			MatchRec r;
+			r.len4096 = 0xFFFF; r.len1024 = 0;
+			r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
+			mr[p] = r;
+			const bool deep_in_run = p >= 3 && sp[-1] == sp[0] && sp[-2] == sp[0] && sp[-3] == sp[0] && sp[1] == sp[0] && sp[2] == sp[0];
+			if (!deep_in_run) heavy[atomicAdd(&a.heavy_count[s], 1u)] = i;
+			else *(heavy + a.in_stride - 1 - atomicAdd(&a.deep_count[s], 1u)) = i;
+		}
+	}
+}
+
+// Wave-cooperative longest_match for one position whose chain is long: 64 candidates per step.
+// Returns the packed MatchRec (lo = len4096 | len1024 << 16, hi = dist4096 | dist1024 << 16), wave-uniform.
+__device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint16_t *keys, const uint32_t *vals, uint32_t L,
+                                                   uint32_t i, uint32_t p, int lane, uint32_t &lo, uint32_t &hi)
+{
+	const uint32_t h = keys[i];
+	const uint32_t lookahead = L - p;
+	const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
+	const uint32_t nil_q = nil_candidate(p, lookahead);
+	const uint8_t *sp = in + p;
+	int best = 0;
+	uint32_t best_q = 0;
+	int len1024 = -1;
+	uint32_t q1024 = 0;
+	for (int r = 0; r < 64; r++) {  // 64 x 64 = max_chain_length 4096 candidates
+		const int64_t j = (int64_t)i - 1 - (int64_t)(r * 64 + lane);
+		const bool in_chain = j >= 0 && keys[j] == h;
+		const uint32_t q = in_chain ? vals[j] : 0u;
+		const uint32_t dist = p - q;
+		const bool term = !in_chain || q == 0 || q == nil_q ||
+		                  ((r == 0 && lane == 0) ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST);
+		const uint64_t tmask = __ballot(term);
+		const int nvalid = tmask ? (__ffsll((long long)tmask) - 1) : 64;
+		int len = 0;
+		if (lane < nvalid && best < max_len) {
+			const uint8_t *mp = in + q;
+			if (mp[best] == sp[best]) {
+				while (len < max_len && mp[len] == sp[len]) len++;
+			}
+		}
+		// longest length in this step, earliest candidate (lowest lane) that reaches it
+		uint64_t cand = __ballot(len > best);
+		if (cand) {
+			for (int b = 8; b >= 0; b--) {
+				const uint64_t mb = __ballot((len >> b) & 1) & cand;
+				if (mb) cand = mb;
+			}
+			const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
+			best = __builtin_amdgcn_readlane(len, win);
+			best_q = (uint32_t)__builtin_amdgcn_readlane((int)q, win);
+		}
+		if (r == 15 && nvalid == 64) { len1024 = best; q1024 = best_q; }  // after exactly 1024 candidates
+		if (best >= max_len || nvalid < 64) break;
+	}
+	if (len1024 < 0) { len1024 = best; q1024 = best_q; }
+	lo = (uint32_t)best | ((uint32_t)len1024 << 16);
+	hi = (best ? p - best_q : 0u) | ((len1024 ? p - q1024 : 0u) << 16);
+}
+
+__global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const size_t base = (size_t)s * a.in_stride;
+	const uint16_t *keys = a.keys_out + base;
+	const uint32_t *vals = a.vals_out + base;
+	uint2 *mr = reinterpret_cast<uint2 *>(a.mr) + base;
+	const uint32_t *heavy = a.heavy_list + base;
+	const uint32_t nheavy = a.heavy_count[s];
+	const int lane = threadIdx.x & 63;
+	for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += gridDim.x * (blockDim.x >> 6)) {
+		const uint32_t i = heavy[e];
+		const uint32_t p = vals[i];
+		uint32_t lo, hi;
+		coop_longest_match(in, keys, vals, L, i, p, lane, lo, hi);
+		if (lane == 0) mr[p] = make_uint2(lo, hi);
+	}
+}
+
+// ------------------------------------------------------------------ 2c. positions deep inside a run of one byte
+// For p with in[p-3..p+2] all equal to b and r further b's ahead (r < max_len), the chain head is p-1
+// and yields exactly r.  Only a candidate q that is r bytes before the END of an earlier run of b,
+// followed by the same byte c = in[p+r], can be longer.  So instead of 4096 chain steps the lane scans
+// the (much shorter) list of run ends backwards.  Chain-length limits translate into position limits
+// through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
+__global__ void __launch_bounds__(256) dfl_run_ends_kernel(DeflateArgs a)
+{
+	// one workgroup per slice: ordered compaction of run ends (runs of >= 3 equal bytes)
+	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t s_base;
+	const int s = blockIdx.x;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_base = 0;
+	__syncthreads();
+	for (uint32_t x0 = 0; x0 < L; x0 += blockDim.x) {
+		const uint32_t x = x0 + threadIdx.x;
+		const bool flag = x >= 3 && x < L && in[x - 1] == in[x - 2] && in[x - 2] == in[x - 3] && in[x] != in[x - 1];
+		const uint64_t bal = __ballot(flag);
+		if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+		__syncthreads();
+		uint32_t wb = 0, tot = 0;
+		for (int w = 0; w < 4; w++) { if (w < wave) wb += wsum[w]; tot += wsum[w]; }
+		const uint32_t base = s_base;
+		if (flag) re[base + wb + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = x;
+		__syncthreads();
+		if (threadIdx.x == 0) s_base = base + tot;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) a.run_end_count[s] = s_base;
+}
+
+__global__ void __launch_bounds__(256) dfl_match_deep_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const size_t base = (size_t)s * a.in_stride;
+	const uint16_t *keys = a.keys_out + base;
+	const uint32_t *vals = a.vals_out + base;
+	uint2 *mr = reinterpret_cast<uint2 *>(a.mr) + base;
+	const uint32_t *deep = a.heavy_list + base + a.in_stride - 1;  // grows downwards from the end
+	const uint32_t ndeep = a.deep_count[s];
+	const uint32_t *re = a.run_ends + base;
+	const uint32_t nre = a.run_end_count[s];
+	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ndeep; e += gridDim.x * blockDim.x) {
+		const uint32_t i = *(deep - e);
+		const uint32_t p = vals[i];
+		const uint32_t h = keys[i];
+		const uint32_t lookahead = L - p;
+		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
+		const uint8_t b = in[p];
+		uint32_t r = 3;
+		while (r < max_len && in[p + r] == b) r++;
+		uint32_t best4 = r, q4 = p - 1, best1 = r, q1 = p - 1;
+		if (r < max_len) {  // (r == max_len never reaches this kernel: the light pass ends at the chain head)
+			const uint8_t c = in[p + r];
+			const uint32_t qw = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1 : 1u;  // dist < MAX_DIST, q != NIL
+			uint32_t qmin4 = qw, qmin1 = qw;
+			if (i >= 4096 && keys[i - 4096] == h) qmin4 = max(qmin4, vals[i - 4096]);
+			if (i >= 1024 && keys[i - 1024] == h) qmin1 = max(qmin1, vals[i - 1024]);
+			// start of p's own run, then the last run end at or before it
+			uint32_t sp = p;
+			while (sp > 0 && in[sp - 1] == b && p - sp < 300) sp--;
+			if (sp > 0 && in[sp - 1] == b) {  // very long run: its start is further than any useful candidate
+				uint32_t lo = 0, hi = nre;   // binary search instead: last run end <= p
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
+				sp = lo ? re[lo - 1] : 0;     // (run ends inside p's run do not exist, so this is <= run start)
+			}
+			uint32_t lo = 0, hi = nre;
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= sp) lo = mid + 1; else hi = mid; }
+			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
+				const uint32_t x = re[t];
+				if (x < qmin4 + r) break;  // q = x - r would fall outside the first 4096 chain entries / the window
+				if (in[x - 1] != b || in[x] != c) continue;
+				uint32_t run = 3;
+				while (run < r && x >= run + 1 && in[x - 1 - run] == b) run++;
+				if (run < r) continue;        // the earlier run is shorter than what p needs
+				const uint32_t q = x - r;
+				uint32_t len = r + 1;
+				while (len < max_len && in[q + len] == in[p + len]) len++;
+				if (len > best4) { best4 = len; q4 = q; }
+				if (q >= qmin1 && len > best1) { best1 = len; q1 = q; }
+				if (best4 >= max_len) break;
+			}
+		}
+		mr[p] = make_uint2(best4 | (best1 << 16), (p - q4) | ((p - q1) << 16));
 	}
 }
 
@@ -660,14 +844,18 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 	}
 }
 
-__global__ void dfl_offsets_kernel(DeflateArgs a, int n)
+__global__ void dfl_offsets2_kernel(DeflateArgs a, int n)
 {
-	// blk_entry := "not entered", postloop flags, for the walk kernel
+	// blk_entry := "not entered" for the walk kernel
 	const size_t per = a.in_stride / 64;
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x)
 		a.blk_entry[i] = 0xFFFFFFFFu;
+}
+
+__global__ void dfl_offsets_kernel(DeflateArgs a, int n)
+{
 	if (blockIdx.x == 0)
-		for (int s = threadIdx.x; s < n; s += blockDim.x) a.postloop_lit[s] = 0;
+		for (int s = threadIdx.x; s < n; s += blockDim.x) { a.postloop_lit[s] = 0; a.heavy_count[s] = 0; a.deep_count[s] = 0; }
 }
 
 }  // namespace
@@ -731,7 +919,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	const size_t total = (size_t)n * a.in_stride;
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(256), dim3(256), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	hipLaunchKernelGGL(dfl_hash_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	size_t tb = sort_temp_bytes;
@@ -739,7 +927,11 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	                                             (unsigned int)total, (unsigned int)n, a.seg_begin, a.seg_end, 0, 15, st)) != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(dfl_match_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_match_deep_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
