@@ -88,7 +88,7 @@ struct Context {
 	DevBuf h_stage;  // pinned host staging (payloads)
 	// device DEFLATE workspaces
 	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
-	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes;
+	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
 	bool z_tables_ready = false;
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
 	float t_dev_deflate_ms = 0;
@@ -400,7 +400,7 @@ int cct_shutdown(void)
 	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage,
 	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
 	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
-	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes};
+	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs};
 	for (DevBuf *b : bufs) b->release();
 	(void)hipEventDestroy(g_ctx.ev_k0);
 	(void)hipEventDestroy(g_ctx.ev_k1);
@@ -596,20 +596,38 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 		for (int i = 0; i < n; i++)
 			if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
 		const size_t zstride = cct_file_bound(width, height, block_size);
-		HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
-		rc = deflate_locked((const uint8_t *)g_ctx.e_payload.p, stride, (const uint32_t *)g_ctx.e_sizes.p, n, hdr13, zstride);
-		if (rc) return rc;
-		HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
-		HIP_TRY(hipMemcpyAsync(h_out_sizes, g_ctx.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_k0, g_ctx.ev_k1));
-		g_ctx.t_deflate_ms = g_ctx.t_dev_deflate_ms;
-		const double t_c0 = now_ms();
-		for (int i = 0; i < n; i++)
-			HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.z_out.p + (size_t)i * zstride, h_out_sizes[i],
-			                       hipMemcpyDeviceToHost, g_ctx.stream));
-		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-		g_ctx.t_d2h_ms = (float)(now_ms() - t_c0);
+		// bounded workspaces: at most 2^28 payload bytes per pass (the corpus config is 3954 slices)
+		const int chunk = (int)std::max<size_t>(1, ((size_t)1 << 28) / stride);
+		g_ctx.t_deflate_ms = 0; g_ctx.t_d2h_ms = 0;
+		for (int c0 = 0; c0 < n; c0 += chunk) {
+			const int nc = std::min(chunk, n - c0);
+			HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
+			rc = deflate_locked((const uint8_t *)g_ctx.e_payload.p + (size_t)c0 * stride, stride,
+			                    (const uint32_t *)g_ctx.e_sizes.p + c0, nc, hdr13, zstride);
+			if (rc) return rc;
+			HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
+			uint32_t *osz = h_out_sizes + c0;
+			HIP_TRY(hipMemcpyAsync(osz, g_ctx.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+			HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+			g_ctx.t_deflate_ms += g_ctx.t_dev_deflate_ms;
+			const double t_c0 = now_ms();
+			// pack the files back to back on the device, one copy into pinned memory, threaded scatter
+			std::vector<size_t> offs(nc + 1, 0);
+			for (int i = 0; i < nc; i++) offs[i + 1] = offs[i] + (((size_t)osz[i] + 15) & ~(size_t)15);
+			const size_t packed_cap = offs[nc];
+			if ((rc = g_ctx.z_packed.ensure(packed_cap + 16))) return rc;
+			if ((rc = g_ctx.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
+			if ((rc = g_ctx.h_stage.ensure(packed_cap + 16))) return rc;
+			HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
+			                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, g_ctx.stream));
+			HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, packed_cap, hipMemcpyDeviceToHost, g_ctx.stream));
+			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+			const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
+			parallel_for(nc, std::min(g_ctx.zlib_threads, 32),
+			             [&](int i) { memcpy(h_out + (size_t)(c0 + i) * out_stride, stg + offs[i], osz[i]); });
+			g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
+		}
 		if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 		return CCT_OK;
 	}

@@ -106,6 +106,22 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 		uint32_t best_q = 0;
 		const uint8_t *sp = in + p;
 		bool done = true;
+		// deep inside a run of one byte the chain head is p-1; unless it already yields max_len the
+		// position goes to dfl_match_deep_kernel without walking the (very long) chain at all
+		const bool deep_in_run = p >= 3 && max_len >= 3 && sp[-1] == sp[0] && sp[-2] == sp[0] && sp[-3] == sp[0] &&
+		                         sp[1] == sp[0] && sp[2] == sp[0];
+		if (deep_in_run) {
+			int r = 3;
+			while (r < max_len && sp[r] == sp[0]) r++;
+			if (r >= max_len) { best = max_len; best_q = p - 1; }
+			else {
+				MatchRec rr;
+				rr.len4096 = 0xFFFF; rr.len1024 = 0; rr.dist4096 = (uint16_t)(i & 0xFFFFu); rr.dist1024 = (uint16_t)(i >> 16);
+				mr[p] = rr;
+				*(heavy + a.in_stride - 1 - atomicAdd(&a.deep_count[s], 1u)) = i;
+				continue;
+			}
+		} else
 		for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
 			if (count == LIGHT_STEPS) { done = false; break; }        // heavy: finish cooperatively
 			const uint32_t q = vals[j];
@@ -134,9 +150,7 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 			r.len4096 = 0xFFFF; r.len1024 = 0;
 			r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
 			mr[p] = r;
-			const bool deep_in_run = p >= 3 && sp[-1] == sp[0] && sp[-2] == sp[0] && sp[-3] == sp[0] && sp[1] == sp[0] && sp[2] == sp[0];
-			if (!deep_in_run) heavy[atomicAdd(&a.heavy_count[s], 1u)] = i;
-			else *(heavy + a.in_stride - 1 - atomicAdd(&a.deep_count[s], 1u)) = i;
+			heavy[atomicAdd(&a.heavy_count[s], 1u)] = i;
 		}
 	}
 }
@@ -361,23 +375,45 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 	}
 }
 
-// ------------------------------------------------------------------ 3b. block-to-block walk (one lane per slice)
-__global__ void dfl_walk_kernel(DeflateArgs a, int n)
+// ------------------------------------------------------------------ 3b. block-to-block walk (one workgroup per slice)
+// The hop chain is serial, so its cost is latency: the exit tables are staged through LDS in windows
+// by the whole workgroup and one lane hops inside the window.
+constexpr int WK_WIN = 4096;
+__global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 {
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= n) return;
+	__shared__ uint32_t w_pos[WK_WIN], w_cnt[WK_WIN];
+	__shared__ uint32_t s_cur, s_syms;
+	const int s = blockIdx.x;
+	(void)n;
 	const uint32_t L = a.in_sizes[s];
 	const size_t base = (size_t)s * a.in_stride;
 	const size_t bbase = (size_t)s * (a.in_stride / 64);
-	uint32_t cur = 0, syms = 0;
-	while (cur < L) {
-		const uint32_t b = cur >> 6;
-		a.blk_entry[bbase + b] = cur;
-		a.blk_symbase[bbase + b] = syms;
-		syms += a.exit_cnt[base + cur];
-		cur = a.exit_pos[base + cur];
+	if (threadIdx.x == 0) { s_cur = 0; s_syms = 0; }
+	__syncthreads();
+	for (;;) {
+		const uint32_t cur0 = s_cur;
+		if (cur0 >= L) break;
+		const uint32_t w0 = cur0 & ~63u;  // window [w0, w0 + WK_WIN)
+		for (uint32_t t = threadIdx.x; t < (uint32_t)WK_WIN; t += blockDim.x) {
+			const uint32_t x = w0 + t;
+			w_pos[t] = x < a.in_stride ? a.exit_pos[base + x] : 0xFFFFFFFFu;
+			w_cnt[t] = x < a.in_stride ? a.exit_cnt[base + x] : 0u;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t cur = cur0, syms = s_syms;
+			while (cur < L && cur - w0 < (uint32_t)WK_WIN) {
+				const uint32_t b = cur >> 6;
+				a.blk_entry[bbase + b] = cur;
+				a.blk_symbase[bbase + b] = syms;
+				syms += w_cnt[cur - w0];
+				cur = w_pos[cur - w0];
+			}
+			s_cur = cur; s_syms = syms;
+		}
+		__syncthreads();
 	}
-	a.total_syms[s] = syms;
+	if (threadIdx.x == 0) a.total_syms[s] = s_syms;
 }
 
 // ------------------------------------------------------------------ 3c. symbols in stream order
@@ -844,6 +880,25 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 	}
 }
 
+// files back to back (exclusive scan of sizes by one workgroup, then a grid copy) for ONE device->host copy
+__global__ void __launch_bounds__(256) dfl_pack_offsets_kernel(const uint32_t *sizes, int n, uint64_t *offsets)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		uint64_t acc = 0;
+		for (int i = 0; i < n; i++) { offsets[i] = acc; acc += (sizes[i] + 15u) & ~15u; }
+		offsets[n] = acc;
+	}
+}
+__global__ void __launch_bounds__(256) dfl_pack_kernel(const uint8_t *src, size_t stride, const uint32_t *sizes,
+                                                       const uint64_t *offsets, uint8_t *dst)
+{
+	const int s = blockIdx.y;
+	const uint32_t n16 = (sizes[s] + 15u) >> 4;
+	const uint4 *in = reinterpret_cast<const uint4 *>(src + (size_t)s * stride);
+	uint4 *out = reinterpret_cast<uint4 *>(dst + offsets[s]);
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 __global__ void dfl_offsets2_kernel(DeflateArgs a, int n)
 {
 	// blk_entry := "not entered" for the walk kernel
@@ -932,12 +987,20 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_match_deep_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
-	hipLaunchKernelGGL(dfl_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_emit_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes, int n, uint64_t *offsets, uint8_t *dst,
+                       hipStream_t st)
+{
+	hipLaunchKernelGGL(dfl_pack_offsets_kernel, dim3(1), dim3(64), 0, st, sizes, n, offsets);
+	hipLaunchKernelGGL(dfl_pack_kernel, dim3(16, n), dim3(256), 0, st, src, stride, sizes, offsets, dst);
 	return hipGetLastError();
 }
 

@@ -6,8 +6,8 @@
 
 A step = one pass of the hot path over one batch: 256 device-resident synthetic 12-bit 512x512
 CT slices (BASELINE config 2) are encoded to byte-exact .cct files (HIP transform+pack kernel,
-payload D2H, DEFLATE level 9) and those files are decoded back to rasters in HBM (INFLATE,
-payload H2D, HIP token/scatter kernel).  Three distinct batches rotate so the working set
+device DEFLATE bit-identical to zlib level 9, one packed D2H) and those files are decoded back to
+rasters in HBM (host INFLATE, payload H2D, HIP token/scatter kernel).  Three distinct batches rotate so the working set
 (3 x 134 MB) exceeds the 256 MiB Infinity Cache.  Slices shard across GPUs with no data-path
 collective (weak scaling: 256 slices per GPU per step); the only exchange is the all-gather of
 the per-slice compressed sizes over RCCL.
@@ -103,6 +103,8 @@ def main():
     zthreads = max(1, ncpu // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
 
+    dev_deflate = C.c_int(0)
+    _ffi.check(L.cct_get_option(b"device_deflate", C.byref(dev_deflate)))
     cfg = cct_hip.default_config()
     cfg["verbose"] = False
     flags, bs, eof, magic, ch, bpc = cct_hip.codec_params(cfg, np.uint16)
@@ -212,7 +214,9 @@ def main():
                 "decode_end_to_end_MPix_s": round(npx / (acc["dec"] / K * 1e-3) / 1e6, 2),
                 "ms": {k: round(acc[k] / K, 3) for k in ("enc_kernel", "d2h", "deflate", "inflate", "dec_kernel", "enc",
                                                          "dec", "gather")},
-                "deflate_threads": zthreads, "host_cpus": ncpu,
+                "deflate": "device (deflate_kernels.hip, byte-identical to zlib 1.2.11 level 9)" if dev_deflate.value
+                else "host libz thread team", "inflate": "host libz thread team",
+                "host_threads": zthreads, "host_cpus": ncpu,
                 "compression_ratio": round(2.0 * npx * K / max(1, acc["file_bytes"]), 4)},
             "device": info["name"], "verified": verified,
             "sizes_gathered": int(np.asarray(all_sizes).size),
