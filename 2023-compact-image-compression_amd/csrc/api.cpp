@@ -78,6 +78,7 @@ struct Context {
 	pid_t pid = 0;
 	int device = -1;
 	hipStream_t stream = nullptr;
+	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
@@ -95,7 +96,8 @@ struct Context {
 	int zlib_threads = 0;
 	int wg_threads = 1024;
 	// timings of the most recent batch call (cct_last_timings)
-	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
+	DevBuf dh_stage;  // pinned host staging of inflated payloads (decode owns it, see g_mu_dec)
 	float t_enc_kernel_ms = 0, t_dec_kernel_ms = 0, t_d2h_ms = 0, t_deflate_ms = 0, t_inflate_ms = 0, t_h2d_ms = 0;
 };
 
@@ -106,7 +108,10 @@ double now_ms()
 }
 
 Context g_ctx;
-std::mutex g_mu;
+std::mutex g_mu;      // device context, stream and every HIP call
+std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
+std::mutex g_mu_dec;  // one cct_decode_batch at a time; its host INFLATE phase runs outside g_mu so that
+                      // another thread's encode (device DEFLATE) can overlap with it
 
 int default_device()
 {
@@ -139,8 +144,12 @@ int ensure_ctx(int device = -1)
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 		return fail(CCT_E_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
 	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_dec, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_k0));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_k1));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_d0));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_d1));
+	g_ctx.dh_stage.pinned_host = true;
 	g_ctx.h_stage.pinned_host = true;
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
@@ -203,6 +212,7 @@ void build_tile_tables(const std::vector<int32_t> &O, int width, ShapeTables &t)
 
 int get_tables(int width, int height, const ShapeTables **out)
 {
+	std::lock_guard<std::mutex> lkl(g_mu_lut);
 	auto key = std::make_pair(width, height);
 	auto it = g_ctx.luts.find(key);
 	if (it != g_ctx.luts.end()) { *out = &it->second; return CCT_OK; }
@@ -350,7 +360,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 }
 
 int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_t *d_sizes, int n, int width,
-                          int height, int bs, int fractal, uint16_t *d_images, uint32_t *d_status)
+                          int height, int bs, int fractal, uint16_t *d_images, uint32_t *d_status, hipStream_t st)
 {
 	const int N = width * height, NB = N / bs;
 	if (stride % 16 != 0) return fail(CCT_E_ARG, "payload stride must be a multiple of 16");
@@ -368,7 +378,7 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	if ((rc = g_ctx.d_jval.ensure(jper))) return rc;
 	a.ws_role = (uint8_t *)g_ctx.d_role.p; a.ws_slot = (uint32_t *)g_ctx.d_slot.p;
 	a.ws_jord = (uint32_t *)g_ctx.d_jord.p; a.ws_jval = (uint8_t *)g_ctx.d_jval.p;
-	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
+	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, st));
 	return CCT_OK;
 }
 
@@ -404,7 +414,11 @@ int cct_shutdown(void)
 	for (DevBuf *b : bufs) b->release();
 	(void)hipEventDestroy(g_ctx.ev_k0);
 	(void)hipEventDestroy(g_ctx.ev_k1);
+	(void)hipEventDestroy(g_ctx.ev_d0);
+	(void)hipEventDestroy(g_ctx.ev_d1);
+	g_ctx.dh_stage.release();
 	(void)hipStreamDestroy(g_ctx.stream);
+	(void)hipStreamDestroy(g_ctx.stream_dec);
 	g_ctx = Context();
 	return CCT_OK;
 }
@@ -721,18 +735,19 @@ int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_
 int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, const uint32_t *d_payload_sizes, int n,
                            int width, int height, int block_size, int fractal, uint16_t *d_images, uint32_t *d_status)
 {
+	std::lock_guard<std::mutex> lkd(g_mu_dec);
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
 	return decode_payload_locked(d_payload, payload_stride, d_payload_sizes, n, width, height, block_size, fractal,
-	                             d_images, d_status);
+	                             d_images, d_status, g_ctx.stream);
 }
 
 int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, int block_size, const char magic[4],
                      uint16_t *images, int images_on_device, size_t images_cap_px, uint32_t *h_status)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::mutex> lkd(g_mu_dec);
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (n == 0) return CCT_OK;
 	cct_header h0;
@@ -746,20 +761,29 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	}
 	if (h0.width == 0 || h0.height == 0) return fail(CCT_E_SHAPE, "empty image");
 	if ((rc = check_shape(n, h0.width, h0.height, block_size))) return rc;
-	if ((rc = ensure_ctx())) return rc;
 	const size_t N = (size_t)h0.width * h0.height;
 	if (images_cap_px < (size_t)n * N) return fail(CCT_E_CAP, "output holds %zu pixels, need %zu", images_cap_px, (size_t)n * N);
 	const size_t stride = cct_payload_stride(h0.width, h0.height, block_size);
-	if ((rc = g_ctx.h_stage.ensure((size_t)n * stride))) return rc;
-	if ((rc = g_ctx.d_payload.ensure((size_t)n * stride))) return rc;
-	if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
-	if ((rc = g_ctx.d_status.ensure((size_t)n * 4))) return rc;
-	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
+	int zthreads = 1;
+	if (!(g_ctx.ready && g_ctx.pid == getpid())) {  // first use in this process: bind the device
+		std::lock_guard<std::mutex> lk(g_mu);
+		if ((rc = ensure_ctx())) return rc;
+	}
+	{  // decode-owned buffers (guarded by g_mu_dec); no device lock, an encode may be in flight
+		HIP_TRY(hipSetDevice(g_ctx.device));
+		if ((rc = g_ctx.dh_stage.ensure((size_t)n * stride))) return rc;
+		if ((rc = g_ctx.d_payload.ensure((size_t)n * stride))) return rc;
+		if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
+		if ((rc = g_ctx.d_status.ensure((size_t)n * 4))) return rc;
+		if (!images_on_device && (rc = g_ctx.d_images.ensure((size_t)n * N * 2))) return rc;
+		zthreads = g_ctx.zlib_threads;
+	}
+	uint8_t *stage = (uint8_t *)g_ctx.dh_stage.p;
 	std::vector<uint32_t> psz(n);
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
-	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421
+	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421 -- host threads, no device lock held
 	const double t_inf0 = now_ms();
-	parallel_for(n, h0.deflate ? g_ctx.zlib_threads : 1, [&](int i) {
+	parallel_for(n, h0.deflate ? zthreads : 1, [&](int i) {
 		const uint8_t *body = h_files + h_offsets[i] + 13;
 		const size_t blen = (size_t)(h_offsets[i + 1] - h_offsets[i]) - 13;
 		uint8_t *dst = stage + (size_t)i * stride;
@@ -774,27 +798,27 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 			else { memcpy(dst, body, blen); psz[i] = (uint32_t)blen; }
 		}
 	});
-	g_ctx.t_inflate_ms = (float)(now_ms() - t_inf0);
-	for (int i = 0; i < n; i++)
-		HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.d_payload.p + (size_t)i * stride, stage + (size_t)i * stride,
-		                       (psz[i] + 15u) & ~15u, hipMemcpyHostToDevice, g_ctx.stream));
-	HIP_TRY(hipMemcpyAsync(g_ctx.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, g_ctx.stream));
-	uint16_t *d_img = images;
-	if (!images_on_device) {
-		if ((rc = g_ctx.d_images.ensure((size_t)n * N * 2))) return rc;
-		d_img = (uint16_t *)g_ctx.d_images.p;
-	}
-	HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
-	rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
-	                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p);
-	if (rc) return rc;
-	HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
+	const float t_inflate = (float)(now_ms() - t_inf0);
 	std::vector<uint32_t> dst(n);
-	HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-	if (!images_on_device)
-		HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, g_ctx.stream));
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-	HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+	{  // device phase on the decode stream (no device lock: the HIP runtime is thread-safe)
+		hipStream_t st = g_ctx.stream_dec;
+		g_ctx.t_inflate_ms = t_inflate;
+		for (int i = 0; i < n; i++)
+			HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.d_payload.p + (size_t)i * stride, stage + (size_t)i * stride,
+			                       (psz[i] + 15u) & ~15u, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(g_ctx.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+		uint16_t *d_img = images_on_device ? images : (uint16_t *)g_ctx.d_images.p;
+		HIP_TRY(hipEventRecord(g_ctx.ev_d0, st));
+		rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
+		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p, st);
+		if (rc) return rc;
+		HIP_TRY(hipEventRecord(g_ctx.ev_d1, st));
+		HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		if (!images_on_device)
+			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+	}
 	int first = CCT_OK;
 	for (int i = 0; i < n; i++) {
 		if (h_status[i] == CCT_OK) {

@@ -77,7 +77,7 @@ __global__ void dfl_hash_kernel(DeflateArgs a)
 // Pass A: one lane per position walks at most LIGHT_STEPS candidates; positions whose chain is
 // longer ("heavy": long runs of one byte put tens of thousands of strings in one bucket) are queued.
 // Pass B: one WAVE per heavy position, 64 candidates per step.
-constexpr int LIGHT_STEPS = 64;
+constexpr int LIGHT_STEPS = 12;
 
 __device__ __forceinline__ uint32_t nil_candidate(uint32_t p, uint32_t lookahead)
 {
@@ -989,7 +989,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(64), 0, st, a);  // one wave: the tree build is one lane, more blocks per CU in flight
 	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_emit_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slices", type=int, default=SLICES_PER_GPU, help="slices per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,47 +114,70 @@ def main():
 
     batches = make_batches(rank, n)
     d_imgs = [cct_hip.DeviceBuffer.from_numpy(b) for b in batches]
-    d_back = cct_hip.DeviceBuffer(batches[0].nbytes)
+    # Two buffer sets: while step k is decoded (host INFLATE + decode kernel) step k+1 is already being
+    # encoded (transform+pack + device DEFLATE).  Two host threads drive the C ABI; ctypes drops the GIL.
     out_stride = L.cct_file_bound(W, H, bs)
-    h_files = np.empty((n, out_stride), dtype=np.uint8)
-    h_sizes = np.zeros(n, dtype=np.uint32)
-    h_psizes = np.zeros(n, dtype=np.uint32)
-    h_status = np.zeros(n, dtype=np.uint32)
-    packed = np.empty(n * out_stride, dtype=np.uint8)
-    offs = np.zeros(n + 1, dtype=np.uint64)
-    tim = (C.c_float * 6)()
+    NSET = 2
+    d_back = [cct_hip.DeviceBuffer(batches[0].nbytes) for _ in range(NSET)]
+    h_files = [np.empty((n, out_stride), dtype=np.uint8) for _ in range(NSET)]
+    h_sizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    h_psizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    h_status = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    packed = [np.empty(n * out_stride, dtype=np.uint8) for _ in range(NSET)]
     acc = {"enc_kernel": 0.0, "d2h": 0.0, "deflate": 0.0, "inflate": 0.0, "dec_kernel": 0.0, "enc": 0.0, "dec": 0.0,
            "gather": 0.0, "payload_bytes": 0, "file_bytes": 0}
+    from concurrent.futures import ThreadPoolExecutor
+    pool_enc, pool_dec = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
+    overlap = not args.no_overlap
 
-    def step(i, record):
-        d_img = d_imgs[i % len(d_imgs)]
+    def enc_step(i, k, record):
         t0 = time.perf_counter()
-        _ffi.check(L.cct_encode_batch(d_img.ptr, 1, n, W, H, bs, flags, eof, magic, ch, bpc,
-                                      h_files.ctypes.data, out_stride, h_sizes.ctypes.data, h_status.ctypes.data,
-                                      h_psizes.ctypes.data, None))
-        t1 = time.perf_counter()
-        all_sizes = gather_sizes(h_sizes, dist, local_rank)  # RCCL all-gather of compressed sizes
-        t2 = time.perf_counter()
-        L.cct_last_timings(tim)
-        ek, d2h, dfl = tim[0], tim[1], tim[2]
-        # files back to back, as a .cct archive would hold them
-        np.cumsum(h_sizes, out=offs[1:])
-        pos = 0
-        for k in range(n):
-            sz = int(h_sizes[k])
-            packed[pos:pos + sz] = h_files[k, :sz]
-            pos += sz
-        t3 = time.perf_counter()
-        _ffi.check(L.cct_decode_batch(packed.ctypes.data, offs.ctypes.data, n, bs, magic, d_back.ptr, 1,
-                                      d_back.nbytes // 2, h_status.ctypes.data))
-        t4 = time.perf_counter()
-        L.cct_last_timings(tim)
+        tm = (C.c_float * 6)()
+        _ffi.check(L.cct_encode_batch(d_imgs[i % len(d_imgs)].ptr, 1, n, W, H, bs, flags, eof, magic, ch, bpc,
+                                      h_files[k].ctypes.data, out_stride, h_sizes[k].ctypes.data,
+                                      h_status[k].ctypes.data, h_psizes[k].ctypes.data, None))
+        L.cct_last_timings(tm)
         if record:
-            acc["enc_kernel"] += ek; acc["d2h"] += d2h; acc["deflate"] += dfl
-            acc["inflate"] += tim[3]; acc["dec_kernel"] += tim[4]
-            acc["enc"] += (t1 - t0) * 1e3; acc["dec"] += (t4 - t3) * 1e3; acc["gather"] += (t2 - t1) * 1e3
-            acc["payload_bytes"] += int(h_psizes.sum()); acc["file_bytes"] += int(h_sizes.sum())
-        return all_sizes
+            acc["enc_kernel"] += tm[0]; acc["d2h"] += tm[1]; acc["deflate"] += tm[2]
+            acc["enc"] += (time.perf_counter() - t0) * 1e3
+            acc["payload_bytes"] += int(h_psizes[k].sum()); acc["file_bytes"] += int(h_sizes[k].sum())
+
+    def dec_step(k, enc_future, record):
+        enc_future.result()
+        t0 = time.perf_counter()
+        tm = (C.c_float * 6)()
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(h_sizes[k], out=offs[1:])
+        buf, pos = packed[k], 0
+        for j in range(n):  # files back to back, as a .cct archive would hold them
+            sz = int(h_sizes[k][j])
+            buf[pos:pos + sz] = h_files[k][j, :sz]
+            pos += sz
+        st = np.zeros(n, dtype=np.uint32)
+        _ffi.check(L.cct_decode_batch(buf.ctypes.data, offs.ctypes.data, n, bs, magic, d_back[k].ptr, 1, n * W * H,
+                                      st.ctypes.data))
+        L.cct_last_timings(tm)
+        if record:
+            acc["inflate"] += tm[3]; acc["dec_kernel"] += tm[4]
+            acc["dec"] += (time.perf_counter() - t0) * 1e3
+
+    in_flight = []
+    state = {"sizes": None}
+
+    def run_steps(first, count, record):
+        for i in range(first, first + count):
+            k = i % NSET
+            while len(in_flight) >= (NSET if overlap else 1):
+                in_flight.pop(0).result()       # buffer set k is free again
+            e = pool_enc.submit(enc_step, i, k, record)
+            in_flight.append(pool_dec.submit(dec_step, k, e, record))
+            e.result()
+            t1 = time.perf_counter()
+            state["sizes"] = gather_sizes(h_sizes[k], dist, local_rank)  # RCCL all-gather of compressed sizes
+            if record:
+                acc["gather"] += (time.perf_counter() - t1) * 1e3
+        while in_flight:
+            in_flight.pop(0).result()
 
     def barrier():
         _ffi.check(L.cct_sync())
@@ -162,12 +186,10 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i, False)
+    run_steps(0, args.warmup, False)
     barrier()
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        all_sizes = step(args.warmup + i, True)
+    run_steps(args.warmup, args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -177,12 +199,14 @@ def main():
         elapsed = float(t.item())
 
     # ---- verification outside the timed region: exact round trip + oracle bytes on a sample
-    last = (args.warmup + args.steps - 1) % len(batches)
-    back = d_back.download(np.uint16, npx).reshape(n, W, H)
+    last_i = args.warmup + args.steps - 1
+    last, kset = last_i % len(batches), last_i % NSET
+    back = d_back[kset].download(np.uint16, npx).reshape(n, W, H)
     verified = bool(np.array_equal(back, batches[last]))
     from oracle import oracle
-    for k in (0, n // 2, n - 1):
-        verified &= oracle.encode(batches[last][k]) == h_files[k, : h_sizes[k]].tobytes()
+    for j in (0, n // 2, n - 1):
+        verified &= oracle.encode(batches[last][j]) == h_files[kset][j, : h_sizes[kset][j]].tobytes()
+    all_sizes = state["sizes"]
 
     if rank == 0:
         K = max(1, args.steps)
