@@ -557,11 +557,14 @@ int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int heigh
 	                             d_payload_sizes, d_status, d_stats, d_roles);
 }
 
-int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
-                     uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
-                     uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status,
-                     uint32_t *h_payload_sizes, cct_slice_stats *h_stats)
+static int encode_batch_impl(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
+                             uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
+                             uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status,
+                             uint32_t *h_payload_sizes, cct_slice_stats *h_stats, uint64_t *h_packed_offsets)
 {
+	// h_packed_offsets != NULL: archive layout -- files back to back in h_out (capacity out_stride bytes in
+	// total), h_packed_offsets[n+1]; needs the device DEFLATE path (or deflate off)
+	const bool packed = h_packed_offsets != nullptr;
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
@@ -570,8 +573,10 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	const size_t N = (size_t)width * height;
 	const size_t stride = cct_payload_stride(width, height, block_size);
 	const bool defl = (flags & CCT_FLAG_DEFLATE) != 0;
-	if (out_stride < (defl ? cct_file_bound(width, height, block_size) : 13 + stride))
+	if (!packed && out_stride < (defl ? cct_file_bound(width, height, block_size) : 13 + stride))
 		return fail(CCT_E_CAP, "out_stride %zu too small", out_stride);
+	if (packed && !(defl && g_ctx.device_deflate))
+		return fail(CCT_E_ARG, "packed output needs deflate_compression with the device DEFLATE path");
 
 	const uint16_t *d_img = images;
 	if (!images_on_device) {
@@ -633,8 +638,29 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 			if ((rc = g_ctx.z_packed.ensure(packed_cap + 16))) return rc;
 			if ((rc = g_ctx.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
 			if ((rc = g_ctx.h_stage.ensure(packed_cap + 16))) return rc;
+			if (packed) {  // archive layout straight into the caller's buffer
+				size_t exact = 0;
+				for (int i = 0; i < nc; i++) exact += osz[i];
+				if (c0 == 0) h_packed_offsets[0] = 0;
+				const uint64_t at = h_packed_offsets[c0];
+				if (at + exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + exact));
+				HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
+				                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 1, g_ctx.stream));
+				HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
+				HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+				const int nt = std::min(g_ctx.zlib_threads, 16);
+				const size_t per = (exact + nt - 1) / nt;
+				const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
+				parallel_for(nt, nt, [&](int t) {
+					const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
+					if (lo < hi) memcpy(h_out + at + lo, stg + lo, hi - lo);
+				});
+				for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
+				g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
+				continue;
+			}
 			HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
-			                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, g_ctx.stream));
+			                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 0, g_ctx.stream));
 			HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, packed_cap, hipMemcpyDeviceToHost, g_ctx.stream));
 			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 			const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
@@ -676,6 +702,25 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
 	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
 	return CCT_OK;
+}
+
+int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
+                     uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
+                     uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status,
+                     uint32_t *h_payload_sizes, cct_slice_stats *h_stats)
+{
+	return encode_batch_impl(images, images_on_device, n, width, height, block_size, flags, eof_byte, magic, channels,
+	                         bytes_per_channel, h_out, out_stride, h_out_sizes, h_status, h_payload_sizes, h_stats, nullptr);
+}
+
+int cct_encode_batch_packed(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
+                            uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
+                            uint8_t *h_archive, size_t archive_cap, uint64_t *h_offsets, uint32_t *h_out_sizes,
+                            uint32_t *h_status, uint32_t *h_payload_sizes, cct_slice_stats *h_stats)
+{
+	if (!h_offsets) return fail(CCT_E_ARG, "h_offsets is required");
+	return encode_batch_impl(images, images_on_device, n, width, height, block_size, flags, eof_byte, magic, channels,
+	                         bytes_per_channel, h_archive, archive_cap, h_out_sizes, h_status, h_payload_sizes, h_stats, h_offsets);
 }
 
 int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, uint8_t *h_out, size_t out_stride,

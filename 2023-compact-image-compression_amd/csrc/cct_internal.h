@@ -99,7 +99,7 @@ struct DeflateArgs {
 hipError_t deflate_init_tables();
 size_t deflate_sort_temp_bytes(size_t total, int n);
 hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes, int n, uint64_t *offsets, uint8_t *dst,
-                       hipStream_t st);
+                       int exact, hipStream_t st);
 hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st);
 
 }  // namespace cct

@@ -881,11 +881,11 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 }
 
 // files back to back (exclusive scan of sizes by one workgroup, then a grid copy) for ONE device->host copy
-__global__ void __launch_bounds__(256) dfl_pack_offsets_kernel(const uint32_t *sizes, int n, uint64_t *offsets)
+__global__ void __launch_bounds__(256) dfl_pack_offsets_kernel(const uint32_t *sizes, int n, uint64_t *offsets, int exact)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
 		uint64_t acc = 0;
-		for (int i = 0; i < n; i++) { offsets[i] = acc; acc += (sizes[i] + 15u) & ~15u; }
+		for (int i = 0; i < n; i++) { offsets[i] = acc; acc += exact ? sizes[i] : ((sizes[i] + 15u) & ~15u); }
 		offsets[n] = acc;
 	}
 }
@@ -996,11 +996,24 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	return hipGetLastError();
 }
 
-hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes, int n, uint64_t *offsets, uint8_t *dst,
-                       hipStream_t st)
+// exact = 1: files touch each other (archive layout); bytes are moved one at a time since the
+// destinations are unaligned
+__global__ void __launch_bounds__(256) dfl_pack_exact_kernel(const uint8_t *src, size_t stride, const uint32_t *sizes,
+                                                             const uint64_t *offsets, uint8_t *dst)
 {
-	hipLaunchKernelGGL(dfl_pack_offsets_kernel, dim3(1), dim3(64), 0, st, sizes, n, offsets);
-	hipLaunchKernelGGL(dfl_pack_kernel, dim3(16, n), dim3(256), 0, st, src, stride, sizes, offsets, dst);
+	const int s = blockIdx.y;
+	const uint32_t nbytes = sizes[s];
+	const uint8_t *in = src + (size_t)s * stride;
+	uint8_t *out = dst + offsets[s];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes, int n, uint64_t *offsets, uint8_t *dst,
+                       int exact, hipStream_t st)
+{
+	hipLaunchKernelGGL(dfl_pack_offsets_kernel, dim3(1), dim3(64), 0, st, sizes, n, offsets, exact);
+	if (exact) hipLaunchKernelGGL(dfl_pack_exact_kernel, dim3(32, n), dim3(256), 0, st, src, stride, sizes, offsets, dst);
+	else hipLaunchKernelGGL(dfl_pack_kernel, dim3(16, n), dim3(256), 0, st, src, stride, sizes, offsets, dst);
 	return hipGetLastError();
 }
 

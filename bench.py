@@ -119,11 +119,12 @@ def main():
     out_stride = L.cct_file_bound(W, H, bs)
     NSET = 2
     d_back = [cct_hip.DeviceBuffer(batches[0].nbytes) for _ in range(NSET)]
-    h_files = [np.empty((n, out_stride), dtype=np.uint8) for _ in range(NSET)]
+    arch_cap = n * out_stride
+    h_arch = [np.empty(arch_cap, dtype=np.uint8) for _ in range(NSET)]   # .cct files back to back (archive layout)
+    h_offs = [np.zeros(n + 1, dtype=np.uint64) for _ in range(NSET)]
     h_sizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
     h_psizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
     h_status = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
-    packed = [np.empty(n * out_stride, dtype=np.uint8) for _ in range(NSET)]
     acc = {"enc_kernel": 0.0, "d2h": 0.0, "deflate": 0.0, "inflate": 0.0, "dec_kernel": 0.0, "enc": 0.0, "dec": 0.0,
            "gather": 0.0, "payload_bytes": 0, "file_bytes": 0}
     from concurrent.futures import ThreadPoolExecutor
@@ -133,9 +134,9 @@ def main():
     def enc_step(i, k, record):
         t0 = time.perf_counter()
         tm = (C.c_float * 6)()
-        _ffi.check(L.cct_encode_batch(d_imgs[i % len(d_imgs)].ptr, 1, n, W, H, bs, flags, eof, magic, ch, bpc,
-                                      h_files[k].ctypes.data, out_stride, h_sizes[k].ctypes.data,
-                                      h_status[k].ctypes.data, h_psizes[k].ctypes.data, None))
+        _ffi.check(L.cct_encode_batch_packed(d_imgs[i % len(d_imgs)].ptr, 1, n, W, H, bs, flags, eof, magic, ch, bpc,
+                                             h_arch[k].ctypes.data, arch_cap, h_offs[k].ctypes.data, h_sizes[k].ctypes.data,
+                                             h_status[k].ctypes.data, h_psizes[k].ctypes.data, None))
         L.cct_last_timings(tm)
         if record:
             acc["enc_kernel"] += tm[0]; acc["d2h"] += tm[1]; acc["deflate"] += tm[2]
@@ -146,16 +147,9 @@ def main():
         enc_future.result()
         t0 = time.perf_counter()
         tm = (C.c_float * 6)()
-        offs = np.zeros(n + 1, dtype=np.uint64)
-        np.cumsum(h_sizes[k], out=offs[1:])
-        buf, pos = packed[k], 0
-        for j in range(n):  # files back to back, as a .cct archive would hold them
-            sz = int(h_sizes[k][j])
-            buf[pos:pos + sz] = h_files[k][j, :sz]
-            pos += sz
         st = np.zeros(n, dtype=np.uint32)
-        _ffi.check(L.cct_decode_batch(buf.ctypes.data, offs.ctypes.data, n, bs, magic, d_back[k].ptr, 1, n * W * H,
-                                      st.ctypes.data))
+        _ffi.check(L.cct_decode_batch(h_arch[k].ctypes.data, h_offs[k].ctypes.data, n, bs, magic, d_back[k].ptr, 1,
+                                      n * W * H, st.ctypes.data))
         L.cct_last_timings(tm)
         if record:
             acc["inflate"] += tm[3]; acc["dec_kernel"] += tm[4]
@@ -205,7 +199,7 @@ def main():
     verified = bool(np.array_equal(back, batches[last]))
     from oracle import oracle
     for j in (0, n // 2, n - 1):
-        verified &= oracle.encode(batches[last][j]) == h_files[kset][j, : h_sizes[kset][j]].tobytes()
+        verified &= oracle.encode(batches[last][j]) == h_arch[kset][int(h_offs[kset][j]):int(h_offs[kset][j + 1])].tobytes()
     all_sizes = state["sizes"]
 
     if rank == 0:

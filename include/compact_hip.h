@@ -129,6 +129,18 @@ int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int wi
                      uint32_t *h_payload_sizes /* may be NULL */,
                      cct_slice_stats *h_stats /* may be NULL */);
 
+/* Same as cct_encode_batch with the files written back to back ("archive" layout, what a corpus
+ * run such as scripts/evaluate.py would store): file i = h_archive[h_offsets[i] .. h_offsets[i+1]),
+ * h_offsets has n+1 entries; this is exactly the input layout of cct_decode_batch.  Needs
+ * CCT_FLAG_DEFLATE and the device DEFLATE path. */
+int cct_encode_batch_packed(const uint16_t *images, int images_on_device, int n, int width, int height,
+                            int block_size, uint32_t flags, int eof_byte, const char magic[4],
+                            int channels, int bytes_per_channel,
+                            uint8_t *h_archive, size_t archive_cap, uint64_t *h_offsets,
+                            uint32_t *h_out_sizes, uint32_t *h_status,
+                            uint32_t *h_payload_sizes /* may be NULL */,
+                            cct_slice_stats *h_stats /* may be NULL */);
+
 /* DEFLATE stage alone, on the device: n byte strings (h_in[h_offsets[i] .. h_offsets[i+1])) ->
  * n zlib streams byte-identical to zlib 1.2.11 compress2(level 9), i.e. CPython's
  * zlib.compress(data, level=9) that the reference calls at core.py:340.  Stream i lands at

@@ -61,3 +61,28 @@ def test_encode_batch_host_and_device_deflate_agree(hip):
     _ffi.check(L.cct_set_option(b"device_deflate", 1))
     dev = hip.encode_batch(imgs, cfg)
     assert host == dev
+
+
+def test_packed_archive_output_equals_strided_output(hip):
+    """cct_encode_batch_packed writes the same files back to back; cct_decode_batch reads that layout."""
+    import ctypes as C
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    cfg = hip.default_config()
+    imgs = np.stack([gi.ct_phantom(70 + i, 256) for i in range(5)])
+    n, w, h = imgs.shape
+    files = hip.encode_batch(imgs, cfg)
+    flags, bs, eof, magic, ch, bpc = hip.codec_params(cfg, imgs.dtype)
+    cap = sum(len(f) for f in files) + 64
+    arch = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    sizes = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.uint32)
+    _ffi.check(L.cct_encode_batch_packed(imgs.ctypes.data, 0, n, w, h, bs, flags, eof, magic, ch, bpc, arch.ctypes.data, cap,
+                                         offs.ctypes.data, sizes.ctypes.data, status.ctypes.data, None, None))
+    assert [arch[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)] == files
+    assert int(offs[n]) == sum(len(f) for f in files)
+    out = np.empty((n, w, h), dtype=np.uint16)
+    st = np.zeros(n, dtype=np.uint32)
+    _ffi.check(L.cct_decode_batch(arch.ctypes.data, offs.ctypes.data, n, bs, magic, out.ctypes.data, 0, out.size, st.ctypes.data))
+    assert np.array_equal(out, imgs)
