@@ -78,6 +78,10 @@ struct Context {
 	pid_t pid = 0;
 	int device = -1;
 	hipStream_t stream = nullptr;
+	hipStream_t stream_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev_zfork = nullptr;
+	int deflate_ways = 2;  // option "deflate_ways" (1..8); 2 measured best on MI355X
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
@@ -337,8 +341,19 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
 	if ((rc = g_ctx.z_out.ensure((size_t)n * out_stride))) return rc;
 	if ((rc = g_ctx.z_outsizes.ensure((size_t)n * 4))) return rc;
-	const size_t tmp = deflate_sort_temp_bytes(E, n);
-	if ((rc = g_ctx.z_sorttmp.ensure(tmp + 256))) return rc;
+	// The pipeline's kernels are latency-bound (one-lane tree builds, serial block walks, long-chain
+	// tails), so the batch is cut into up to DEFLATE_WAYS slice ranges that run concurrently on their
+	// own streams and share the chip.
+	const int ways = std::max(1, std::min(g_ctx.deflate_ways, n));
+	const int per_way = (n + ways - 1) / ways;
+	const size_t tmp = (deflate_sort_temp_bytes((size_t)per_way * in_stride, per_way) + 511) & ~(size_t)255;
+	if ((rc = g_ctx.z_sorttmp.ensure(tmp * ways + 256))) return rc;
+	for (int w = 0; w < ways; w++)
+		if (!g_ctx.stream_z[w]) {
+			HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_z[w], hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_z[w], hipEventDisableTiming));
+		}
+	if (!g_ctx.ev_zfork) HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_zfork, hipEventDisableTiming));
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
 	a.keys_in = (uint16_t *)g_ctx.z_keys_in.p; a.keys_out = (uint16_t *)g_ctx.z_keys_out.p;
@@ -355,7 +370,27 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.max_blocks = max_blocks;
 	a.out = (uint8_t *)g_ctx.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)g_ctx.z_outsizes.p;
 	memcpy(a.header13, header13, 13);
-	HIP_TRY(launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream));
+	HIP_TRY(hipEventRecord(g_ctx.ev_zfork, g_ctx.stream));  // inputs are produced on the main stream
+	for (int w = 0; w < ways; w++) {
+		const int s0 = w * per_way, ns = std::min(per_way, n - s0);
+		if (ns <= 0) break;
+		DeflateArgs b = a;
+		const size_t eo = (size_t)s0 * in_stride, bo = (size_t)s0 * (in_stride / 64), mo = (size_t)s0 * max_blocks;
+		b.in += eo; b.in_sizes += s0;
+		b.keys_in += eo; b.keys_out += eo; b.vals_in += eo; b.vals_out += eo;
+		b.seg_begin += s0; b.seg_end += s0; b.total_syms += s0; b.postloop_lit += s0; b.n_blocks += s0; b.adler += s0;
+		b.heavy_count += s0; b.deep_count += s0; b.run_end_count += s0;
+		b.mr = (uint8_t *)b.mr + eo * 8; b.heavy_list += eo; b.sym += eo; b.run_ends += eo;
+		b.rec32 += eo; b.exit_pos += eo; b.exit_cnt += eo;
+		b.blk_entry += bo; b.blk_symbase += bo;
+		b.blk_end += mo; b.block_meta += mo; b.block_tables += mo;
+		b.out += (size_t)s0 * out_stride; b.out_sizes += s0;
+		hipStream_t st = g_ctx.stream_z[w];
+		HIP_TRY(hipStreamWaitEvent(st, g_ctx.ev_zfork, 0));
+		HIP_TRY(launch_deflate(b, ns, (uint8_t *)g_ctx.z_sorttmp.p + (size_t)w * tmp, tmp, st));
+		HIP_TRY(hipEventRecord(g_ctx.ev_z[w], st));
+		HIP_TRY(hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_z[w], 0));  // join
+	}
 	return CCT_OK;
 }
 
@@ -896,6 +931,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "deflate_ways")) { if (value < 1 || value > 8) return fail(CCT_E_ARG, "deflate_ways must be 1..8"); g_ctx.deflate_ways = value; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -908,6 +944,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
+	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

@@ -104,6 +104,8 @@ def main():
     zthreads = max(1, ncpu // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
 
+    if os.environ.get("CCT_DEFLATE_WAYS"):
+        _ffi.check(L.cct_set_option(b"deflate_ways", int(os.environ["CCT_DEFLATE_WAYS"])))
     dev_deflate = C.c_int(0)
     _ffi.check(L.cct_get_option(b"device_deflate", C.byref(dev_deflate)))
     cfg = cct_hip.default_config()
