@@ -212,6 +212,13 @@ def main():
         alg_bytes = 2.0 * npx  # HBM-read definition, 2 B per pixel per launch
         achieved = alg_bytes / (enc_kernel_ms * 1e-3) / 1e9
         payload_per_launch = acc["payload_bytes"] / K
+        traffic, traffic_src = None, None
+        try:  # PMC traffic is collected by separate rocprofv3 --pmc runs (it cannot be read from inside this process)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_encode.json")) as f:
+                pmc = json.load(f)
+            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_encode.json (FETCH_SIZE x2 + WRITE_SIZE, same 256-slice launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "MPixels/s encode+decode, 12-bit 512x512 CT batch, bytes-exact",
             "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,7 +230,7 @@ def main():
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)"},
             "roofline": {"kernel": "encode_tiles_kernel (transform+pack, image -> token payload)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_plus_write_GBs": round((alg_bytes + payload_per_launch) / (enc_kernel_ms * 1e-3) / 1e9, 1),
                          "avg_kernel_ms": round(enc_kernel_ms, 4)},
