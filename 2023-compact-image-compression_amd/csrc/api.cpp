@@ -7,6 +7,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -81,7 +83,7 @@ struct Context {
 	hipStream_t stream_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipEvent_t ev_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipEvent_t ev_zfork = nullptr;
-	int deflate_ways = 2;  // option "deflate_ways" (1..8); 2 measured best on MI355X
+	int deflate_ways = 1;  // option "deflate_ways" (1..8): 2 is ~8 % faster alone but unstable next to a concurrent decode stream
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
@@ -256,19 +258,64 @@ int check_shape(int n, int width, int height, int bs)
 	return CCT_OK;
 }
 
-// run fn(i) for i in [0, n) on a team of host threads
+// Persistent host thread team: fn(i) for i in [0, n).  Spawning 256 threads per call costs more than the
+// INFLATE work they do, so workers are kept (and re-created in a forked child, where they do not exist).
+class HostTeam {
+public:
+	template <class F>
+	void run(int n, int threads, F fn)
+	{
+		if (n <= 0) return;
+		const int nt = std::max(1, std::min(threads, n));
+		if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+		std::unique_lock<std::mutex> lk(m_);
+		if (pid_ != getpid()) {  // forked child: the parent's workers are not here
+			nworkers_ = 0;
+			pid_ = getpid();
+		}
+		while (nworkers_ < nt - 1) { std::thread([this] { loop(); }).detach(); nworkers_++; }  // daemon workers
+		job_ = [&fn](int i) { fn(i); };
+		n_ = n; next_.store(0); pending_ = std::min(nt - 1, nworkers_); want_ = pending_; gen_++;
+		cv_.notify_all();
+		lk.unlock();
+		for (int i; (i = next_.fetch_add(1)) < n;) fn(i);  // the caller works too
+		lk.lock();
+		done_.wait(lk, [this] { return pending_ == 0; });
+		job_ = nullptr;
+	}
+private:
+	void loop()
+	{
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(m_);
+		for (;;) {
+			cv_.wait(lk, [&] { return gen_ != seen && want_ > 0; });
+			seen = gen_;
+			want_--;
+			auto job = job_;
+			const int n = n_;
+			lk.unlock();
+			for (int i; (i = next_.fetch_add(1)) < n;) job(i);
+			lk.lock();
+			if (--pending_ == 0) done_.notify_all();
+		}
+	}
+	std::mutex m_;
+	std::condition_variable cv_, done_;
+	int nworkers_ = 0;
+	std::function<void(int)> job_;
+	std::atomic<int> next_{0};
+	int n_ = 0, pending_ = 0, want_ = 0;
+	uint64_t gen_ = 0;
+	pid_t pid_ = getpid();
+};
+// never destroyed: detached workers may still wait on the condition variables at process exit
+HostTeam &g_team_enc = *new HostTeam, &g_team_dec = *new HostTeam;  // encode- and decode-side host phases may overlap
+
 template <class F>
-void parallel_for(int n, int threads, F fn)
+void parallel_for(int n, int threads, F fn, HostTeam &team = g_team_enc)
 {
-	if (n <= 0) return;
-	const int nt = std::max(1, std::min(threads, n));
-	if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-	std::atomic<int> next(0);
-	std::vector<std::thread> team;
-	team.reserve(nt);
-	for (int t = 0; t < nt; t++)
-		team.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
-	for (auto &th : team) th.join();
+	team.run(n, threads, fn);
 }
 
 int encode_payload_locked(const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
@@ -863,7 +910,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
 	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421 -- host threads, no device lock held
 	const double t_inf0 = now_ms();
-	parallel_for(n, h0.deflate ? zthreads : 1, [&](int i) {
+	g_team_dec.run(n, h0.deflate ? zthreads : 1, [&](int i) {
 		const uint8_t *body = h_files + h_offsets[i] + 13;
 		const size_t blen = (size_t)(h_offsets[i + 1] - h_offsets[i]) - 13;
 		uint8_t *dst = stage + (size_t)i * stride;

@@ -830,7 +830,21 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 	const uint32_t *sym = a.sym + (size_t)s * a.in_stride + bm.first_sym;
 	const bool dyn = bm.type == 2;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// code tables of this block in LDS; code bits of 256 symbols are merged into LDS words first, so the
+	// output sees one atomic per 32-bit word instead of two or three per symbol
+	__shared__ uint16_t t_lcode[L_CODES + 2], t_dcode[D_CODES + 2];
+	__shared__ uint8_t t_llen[L_CODES + 2], t_dlen[D_CODES + 2];
+	__shared__ uint32_t wbuf[400];  // 256 symbols x <= 48 bits = 384 words, + alignment word
+	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) {
+		t_lcode[i] = dyn ? bt->lcode[i] : c_static_lcode[i];
+		t_llen[i] = dyn ? bt->llen[i] : c_static_llen[i];
+	}
+	if (threadIdx.x < D_CODES) {
+		t_dcode[threadIdx.x] = dyn ? bt->dcode[threadIdx.x] : c_static_dcode[threadIdx.x];
+		t_dlen[threadIdx.x] = dyn ? bt->dlen[threadIdx.x] : (uint8_t)5;
+	}
 	if (threadIdx.x == 0) s_run = bit;
+	for (int i = threadIdx.x; i < 400; i += blockDim.x) wbuf[i] = 0;
 	__syncthreads();
 	for (uint32_t base = 0; base <= bm.nsym; base += blockDim.x) {  // one extra slot for END_BLOCK
 		const uint32_t i = base + threadIdx.x;
@@ -841,25 +855,25 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 			uint32_t dist = v >> 16;
 			const uint32_t lc = v & 0xFFu;
 			if (dist == 0) {
-				bits = dyn ? bt->lcode[lc] : c_static_lcode[lc];
-				nb = dyn ? bt->llen[lc] : c_static_llen[lc];
+				bits = t_lcode[lc];
+				nb = t_llen[lc];
 			} else {  // compress_block, trees.c:1070-1110
 				int code = c_length_code[lc];
 				const int lsym = code + 256 + 1;
-				bits = dyn ? bt->lcode[lsym] : c_static_lcode[lsym];
-				nb = dyn ? bt->llen[lsym] : c_static_llen[lsym];
+				bits = t_lcode[lsym];
+				nb = t_llen[lsym];
 				int extra = c_extra_lbits[code];
 				if (extra) { bits |= (uint64_t)(lc - c_base_length[code]) << nb; nb += extra; }
 				dist--;
 				code = d_code(dist);
-				bits |= (uint64_t)(dyn ? bt->dcode[code] : c_static_dcode[code]) << nb;
-				nb += dyn ? bt->dlen[code] : 5;
+				bits |= (uint64_t)t_dcode[code] << nb;
+				nb += t_dlen[code];
 				extra = c_extra_dbits[code];
 				if (extra) { bits |= (uint64_t)(dist - c_base_dist[code]) << nb; nb += extra; }
 			}
 		} else if (i == bm.nsym) {
-			bits = dyn ? bt->lcode[END_BLOCK] : c_static_lcode[END_BLOCK];
-			nb = dyn ? bt->llen[END_BLOCK] : c_static_llen[END_BLOCK];
+			bits = t_lcode[END_BLOCK];
+			nb = t_llen[END_BLOCK];
 		}
 		// exclusive scan of bit counts over the workgroup
 		uint32_t inc = (uint32_t)nb;
@@ -873,8 +887,22 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 		uint32_t wb = 0, tot = 0;
 		for (int w = 0; w < 4; w++) { if (w < wave) wb += wsum[w]; tot += wsum[w]; }
 		const uint64_t run = s_run;
-		or_bits(words, run + wb + inc - (uint32_t)nb, bits, nb);
+		const uint32_t lbit = (uint32_t)(run & 31) + wb + inc - (uint32_t)nb;  // bit position inside wbuf
+		if (nb) {
+			const uint32_t w0 = lbit >> 5, sh = lbit & 31;
+			const uint64_t lo = bits << sh;
+			atomicOr(&wbuf[w0], (uint32_t)lo);
+			if (sh + nb > 32) atomicOr(&wbuf[w0 + 1], (uint32_t)(lo >> 32));
+			if (sh + nb > 64) atomicOr(&wbuf[w0 + 2], (uint32_t)(bits >> (64 - sh)));
+		}
 		__syncthreads();
+		const uint32_t nwords = ((uint32_t)(run & 31) + tot + 31) >> 5;
+		const uint64_t gw = run >> 5;
+		for (uint32_t k = threadIdx.x; k < nwords; k += blockDim.x) {
+			const uint32_t v = wbuf[k];
+			if (v) atomicOr(&words[gw + k], v);  // edge words are shared with the neighbouring 256 symbols / blocks
+			wbuf[k] = 0;
+		}
 		if (threadIdx.x == 0) s_run = run + tot;
 		__syncthreads();
 	}

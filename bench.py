@@ -102,6 +102,8 @@ def main():
     info = cct_hip.device_info()
     ncpu = os.cpu_count() or 1
     zthreads = max(1, ncpu // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    if os.environ.get("CCT_HOST_THREADS"):
+        zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
 
     if os.environ.get("CCT_DEFLATE_WAYS"):

@@ -324,3 +324,39 @@ def test_tile_path_equals_generic_path(hip, n_px):
     assert res[0][4] == res[1][4]
     for i in range(n):
         assert res[0][4][i] == oracle.encode(imgs[i], deflate=False)[13:]
+
+
+def test_config4_1024_square_batch(hip):
+    """BASELINE configs[3]: 1024x1024 slices, block_size 16 -> tile kernel with role[] in the HBM
+    workspace (65536 blocks do not fit LDS next to the rings); checked against the oracle."""
+    from oracle import oracle
+    cfg = hip.default_config()
+    imgs = np.stack([gi.ct_phantom(80 + i, 1024) for i in range(4)])
+    files, info = hip.encode_batch(imgs, cfg, return_info=True)
+    for img, f, st in zip(imgs, files, info):
+        ref, rst = oracle.encode(img, return_stats=True)
+        assert f == ref
+        assert (st["n_jump"], st["n_difficult"], st["payload_len"]) == (rst.n_jump, rst.n_difficult, rst.payload_len)
+    assert np.array_equal(hip.decode_batch(files, cfg), imgs)
+
+
+def test_more_slices_than_compute_units(hip):
+    """BASELINE configs[2] shape of work: many more slices than CUs in one call (here 700 small ones),
+    contiguous shards as cct_hip.parallel.shard_range would hand them out; sample checked vs the oracle."""
+    from oracle import oracle
+    from cct_hip.parallel import shard_range
+    cfg = hip.default_config()
+    base = [gi.ct_phantom(90 + i, 128) for i in range(20)]
+    rng = np.random.default_rng(3)
+    n = 700
+    imgs = np.stack([np.clip(base[i % 20].astype(np.int32) + rng.integers(-8, 9, size=(128, 128)), 0, 2047).astype(np.uint16)
+                     for i in range(n)])
+    files = []
+    for r in range(3):  # three "ranks"
+        lo, hi = shard_range(n, r, 3)
+        files += hip.encode_batch(imgs[lo:hi], cfg)
+    assert len(files) == n
+    for i in (0, 233, 234, 466, 699):
+        assert files[i] == oracle.encode(imgs[i])
+    back = hip.decode_batch(files, cfg)
+    assert np.array_equal(back, imgs)
