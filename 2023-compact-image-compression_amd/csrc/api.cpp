@@ -98,11 +98,13 @@ struct Context {
 	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
 	bool z_tables_ready = false;
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
+	int device_inflate = 1;  // option "device_inflate": 0 = INFLATE stage on the host thread team (libz)
+	DevBuf d_arch, d_archoffs, d_zstatus;
 	float t_dev_deflate_ms = 0;
 	int zlib_threads = 0;
 	int wg_threads = 1024;
 	// timings of the most recent batch call (cct_last_timings)
-	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
 	DevBuf dh_stage;  // pinned host staging of inflated payloads (decode owns it, see g_mu_dec)
 	float t_enc_kernel_ms = 0, t_dec_kernel_ms = 0, t_d2h_ms = 0, t_deflate_ms = 0, t_inflate_ms = 0, t_h2d_ms = 0;
 };
@@ -155,6 +157,8 @@ int ensure_ctx(int device = -1)
 	HIP_TRY(hipEventCreate(&g_ctx.ev_k1));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_d0));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_d1));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec0));
+	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec1));
 	g_ctx.dh_stage.pinned_host = true;
 	g_ctx.h_stage.pinned_host = true;
 	g_ctx.device = dev;
@@ -908,6 +912,46 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	uint8_t *stage = (uint8_t *)g_ctx.dh_stage.p;
 	std::vector<uint32_t> psz(n);
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
+	const bool dev_inflate = h0.deflate && g_ctx.device_inflate;
+	std::vector<uint32_t> dst(n), zst(n, 0);
+	if (dev_inflate) {
+		// INFLATE on the device (inflate_kernels.hip): the archive goes up as it is, payloads never touch the host
+		const uint64_t a0 = h_offsets[0], a1 = h_offsets[n];
+		const size_t abytes = (size_t)(a1 - a0), apad = (abytes + 31) & ~(size_t)15;
+		HIP_TRY(hipSetDevice(g_ctx.device));
+		if ((rc = g_ctx.d_arch.ensure(apad + 16))) return rc;
+		if ((rc = g_ctx.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
+		if ((rc = g_ctx.d_zstatus.ensure((size_t)n * 4))) return rc;
+		std::vector<uint64_t> rel(n + 1);
+		for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
+		hipStream_t st = g_ctx.stream_dec;
+		const double t_inf0 = now_ms();
+		HIP_TRY(hipMemcpyAsync(g_ctx.d_arch.p, h_files + a0, abytes, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(g_ctx.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+		InflateArgs ia{};
+		ia.in = (const uint8_t *)g_ctx.d_arch.p; ia.in_total = apad;
+		ia.offsets = (const uint64_t *)g_ctx.d_archoffs.p; ia.skip = 13;
+		ia.out = (uint8_t *)g_ctx.d_payload.p; ia.out_stride = stride;
+		ia.out_sizes = (uint32_t *)g_ctx.d_sizes.p; ia.status = (uint32_t *)g_ctx.d_zstatus.p;
+		HIP_TRY(hipEventRecord(g_ctx.ev_d0, st));
+		HIP_TRY(launch_inflate(ia, n, st));
+		HIP_TRY(hipEventRecord(g_ctx.ev_d1, st));
+		uint16_t *d_img = images_on_device ? images : (uint16_t *)g_ctx.d_images.p;
+		hipEvent_t ev_k = g_ctx.ev_k_dec0, ev_k1 = g_ctx.ev_k_dec1;
+		HIP_TRY(hipEventRecord(ev_k, st));
+		rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
+		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p, st);
+		if (rc) return rc;
+		HIP_TRY(hipEventRecord(ev_k1, st));
+		HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(zst.data(), g_ctx.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		if (!images_on_device)
+			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipEventElapsedTime(&g_ctx.t_inflate_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, ev_k, ev_k1));
+		(void)t_inf0;
+	} else {
 	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421 -- host threads, no device lock held
 	const double t_inf0 = now_ms();
 	g_team_dec.run(n, h0.deflate ? zthreads : 1, [&](int i) {
@@ -926,7 +970,6 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		}
 	});
 	const float t_inflate = (float)(now_ms() - t_inf0);
-	std::vector<uint32_t> dst(n);
 	{  // device phase on the decode stream (no device lock: the HIP runtime is thread-safe)
 		hipStream_t st = g_ctx.stream_dec;
 		g_ctx.t_inflate_ms = t_inflate;
@@ -946,10 +989,12 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
 	}
+	}
 	int first = CCT_OK;
 	for (int i = 0; i < n; i++) {
 		if (h_status[i] == CCT_OK) {
-			if (dst[i] & CCT_ST_STREAM) h_status[i] = CCT_E_STREAM;
+			if (zst[i] & CCT_ST_ZLIB) h_status[i] = CCT_E_ZLIB;
+			else if ((zst[i] | dst[i]) & CCT_ST_STREAM) h_status[i] = CCT_E_STREAM;
 			else if (dst[i] & CCT_ST_OVERFLOW) h_status[i] = CCT_E_OVERFLOW;
 		}
 		if (h_status[i] != CCT_OK && first == CCT_OK) {
@@ -978,6 +1023,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { if (value < 1 || value > 8) return fail(CCT_E_ARG, "deflate_ways must be 1..8"); g_ctx.deflate_ways = value; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
@@ -992,6 +1038,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
+	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

@@ -102,4 +102,13 @@ hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes,
                        int exact, hipStream_t st);
 hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st);
 
+// ---- device INFLATE (inflate_kernels.hip) ----------------------------------------------------
+struct InflateArgs {
+	const uint8_t *in; uint64_t in_total;   // archive bytes on the device (padded to 16), total size
+	const uint64_t *offsets; int skip;      // stream i = in[offsets[i] + skip .. offsets[i+1])
+	uint8_t *out; size_t out_stride;        // inflated payloads
+	uint32_t *out_sizes, *status;           // status: CCT_ST_ZLIB / CCT_ST_STREAM bits
+};
+hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st);
+
 }  // namespace cct

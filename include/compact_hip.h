@@ -57,6 +57,7 @@ extern "C" {
 #define CCT_ST_CAP 2u        /* encode: payload stride too small */
 #define CCT_ST_OVERFLOW 4u   /* decode: CCT_E_OVERFLOW condition */
 #define CCT_ST_STREAM 8u     /* decode: CCT_E_STREAM condition */
+#define CCT_ST_ZLIB 16u      /* decode: CCT_E_ZLIB condition (device INFLATE) */
 
 typedef struct cct_header {  /* the 13-byte .cct header (core.py:193-210 / 385-402) */
 	int32_t width;             /* image.shape[0] */

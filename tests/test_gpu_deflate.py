@@ -86,3 +86,61 @@ def test_packed_archive_output_equals_strided_output(hip):
     st = np.zeros(n, dtype=np.uint32)
     _ffi.check(L.cct_decode_batch(arch.ctypes.data, offs.ctypes.data, n, bs, magic, out.ctypes.data, 0, out.size, st.ctypes.data))
     assert np.array_equal(out, imgs)
+
+
+def _decode_both(hip, files, cfg):
+    """decode a batch with the device INFLATE and with libz on the host; both must agree"""
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    outs = []
+    for dev in (1, 0):
+        _ffi.check(L.cct_set_option(b"device_inflate", dev))
+        try:
+            outs.append(hip.decode_batch(files, cfg))
+        finally:
+            _ffi.check(L.cct_set_option(b"device_inflate", 1))
+    assert np.array_equal(outs[0], outs[1])
+    return outs[0]
+
+
+def test_device_inflate_golden_and_real_slices(hip):
+    cfg = hip.default_config()
+    imgs = np.stack([gi.load_slice("slice0671"), gi.load_slice("slice3706"), gi.ct_phantom(0), gi.ct_phantom(1)])
+    with open(os.path.join(gi.GOLDEN, "slice0671.cct"), "rb") as f:
+        ref0671 = f.read()  # the reference's own encoder output
+    from oracle import oracle
+    files = [ref0671] + [oracle.encode(im) for im in imgs[1:]]
+    assert np.array_equal(_decode_both(hip, files, cfg), imgs)
+
+
+def test_device_inflate_streams_from_other_encoders(hip):
+    """Streams our DEFLATE would never write: other levels (fixed-Huffman blocks at level 1 on tiny inputs,
+    different block splits), stored blocks (level 0 and incompressible data)."""
+    cfg = hip.default_config()
+    cfg["encoder"]["deflate_compression"] = False
+    raw = hip.encode_batch(np.stack([gi.ct_phantom(5, 128), gi.ct_phantom(6, 128)]), cfg)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 2048, size=(128, 128)).astype(np.uint16)
+    raw.append(hip.encode_batch(noise[None], cfg)[0])
+    imgs = np.stack([gi.ct_phantom(5, 128), gi.ct_phantom(6, 128), noise])
+    cfg["encoder"]["deflate_compression"] = True
+    for level in (0, 1, 6, 9):
+        files = [r[:12] + b"\x01" + zlib.compress(r[13:], level) for r in raw]
+        assert np.array_equal(_decode_both(hip, files, cfg), imgs)
+    # raw deflate features: zlib streams with trailing garbage decode fine (zlib.decompress ignores it)
+    files = [r[:12] + b"\x01" + zlib.compress(r[13:], 9) + b"trailing" for r in raw]
+    assert np.array_equal(hip.decode_batch(files, cfg), imgs)
+
+
+def test_device_inflate_rejects_bad_streams_like_zlib(hip):
+    cfg = hip.default_config()
+    good = hip.encode_batch(gi.ct_phantom(9, 128)[None], cfg)[0]
+    bad_adler = good[:-1] + bytes([good[-1] ^ 1])
+    truncated = good[: len(good) - 9]
+    bad_header = good[:13] + b"\x78\xdb" + good[15:]
+    bad_block = good[:15] + b"\xff\xff\xff" + good[18:]
+    for blob in (bad_adler, truncated, bad_header, bad_block):
+        with pytest.raises(zlib.error):
+            zlib.decompress(blob[13:])
+        with pytest.raises(zlib.error):
+            hip.decode_batch([blob], cfg)
