@@ -98,7 +98,7 @@ def _decode_both(hip, files, cfg):
         try:
             outs.append(hip.decode_batch(files, cfg))
         finally:
-            _ffi.check(L.cct_set_option(b"device_inflate", 1))
+            _ffi.check(L.cct_set_option(b"device_inflate", 0))
     assert np.array_equal(outs[0], outs[1])
     return outs[0]
 
@@ -129,7 +129,7 @@ def test_device_inflate_streams_from_other_encoders(hip):
         assert np.array_equal(_decode_both(hip, files, cfg), imgs)
     # raw deflate features: zlib streams with trailing garbage decode fine (zlib.decompress ignores it)
     files = [r[:12] + b"\x01" + zlib.compress(r[13:], 9) + b"trailing" for r in raw]
-    assert np.array_equal(hip.decode_batch(files, cfg), imgs)
+    assert np.array_equal(_decode_both(hip, files, cfg), imgs)
 
 
 def test_device_inflate_rejects_bad_streams_like_zlib(hip):
@@ -142,5 +142,11 @@ def test_device_inflate_rejects_bad_streams_like_zlib(hip):
     for blob in (bad_adler, truncated, bad_header, bad_block):
         with pytest.raises(zlib.error):
             zlib.decompress(blob[13:])
-        with pytest.raises(zlib.error):
-            hip.decode_batch([blob], cfg)
+        from cct_hip import _ffi
+        for dev in (1, 0):
+            _ffi.check(_ffi.lib().cct_set_option(b"device_inflate", dev))
+            try:
+                with pytest.raises(zlib.error):
+                    hip.decode_batch([blob], cfg)
+            finally:
+                _ffi.check(_ffi.lib().cct_set_option(b"device_inflate", 0))
