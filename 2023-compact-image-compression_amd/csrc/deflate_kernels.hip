@@ -85,6 +85,22 @@ __device__ __forceinline__ uint32_t nil_candidate(uint32_t p, uint32_t lookahead
 	return (lookahead < (uint32_t)MIN_LOOKAHEAD && p >= 32506u + 32768u && (p - 32506u) % 32768u == 0) ? p - 32506u : 0xFFFFFFFFu;
 }
 
+// number of bytes equal to sp[0] starting at sp, capped at cap (<= bytes available); 8 bytes per step
+__device__ __forceinline__ uint32_t run_ahead(const uint8_t *sp, uint32_t cap)
+{
+	const uint64_t pat = 0x0101010101010101ull * sp[0];
+	uint32_t r = 0;
+	while (r + 8 <= cap) {
+		uint64_t w;
+		__builtin_memcpy(&w, sp + r, 8);
+		const uint64_t d = w ^ pat;
+		if (d) return r + ((uint32_t)__ffsll((long long)d) - 1u) / 8u;
+		r += 8;
+	}
+	while (r < cap && sp[r] == sp[0]) r++;
+	return r;
+}
+
 __global__ void dfl_match_kernel(DeflateArgs a)
 {
 	const int s = blockIdx.y;
@@ -106,17 +122,16 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 		uint32_t best_q = 0;
 		const uint8_t *sp = in + p;
 		bool done = true;
-		// deep inside a run of one byte the chain head is p-1; unless it already yields max_len the
-		// position goes to dfl_match_deep_kernel without walking the (very long) chain at all
-		const bool deep_in_run = p >= 3 && max_len >= 3 && sp[-1] == sp[0] && sp[-2] == sp[0] && sp[-3] == sp[0] &&
-		                         sp[1] == sp[0] && sp[2] == sp[0];
-		if (deep_in_run) {
-			int r = 3;
-			while (r < max_len && sp[r] == sp[0]) r++;
-			if (r >= max_len) { best = max_len; best_q = p - 1; }
+		// strings that START a run of three equal bytes share one bucket with every other position of
+		// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
+		// the list of run ends instead of walking the chain
+		const bool in_run = max_len >= 3 && sp[1] == sp[0] && sp[2] == sp[0];
+		if (in_run) {
+			const int r = (int)run_ahead(sp, (uint32_t)max_len);
+			if (p >= 2 && sp[-1] == sp[0] && r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
 			else {
-				MatchRec rr;
-				rr.len4096 = 0xFFFF; rr.len1024 = 0; rr.dist4096 = (uint16_t)(i & 0xFFFFu); rr.dist1024 = (uint16_t)(i >> 16);
+				MatchRec rr;  // sentinel; len1024 hands the run length to dfl_match_run_kernel
+				rr.len4096 = 0xFFFF; rr.len1024 = (uint16_t)r; rr.dist4096 = (uint16_t)(i & 0xFFFFu); rr.dist1024 = (uint16_t)(i >> 16);
 				mr[p] = rr;
 				*(heavy + a.in_stride - 1 - atomicAdd(&a.deep_count[s], 1u)) = i;
 				continue;
@@ -233,34 +248,71 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a)
 // through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
 __global__ void __launch_bounds__(256) dfl_run_ends_kernel(DeflateArgs a)
 {
-	// one workgroup per slice: ordered compaction of run ends (runs of >= 3 equal bytes)
+	// one workgroup per slice: ordered compaction of the ends AND starts of runs of >= 3 equal bytes, four
+	// positions per lane.  The k-th start belongs to the k-th end, which gives the run length without scanning.
+	// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
 	__shared__ uint32_t wsum[4];
-	__shared__ uint32_t s_base;
+	__shared__ uint32_t s_base_e, s_base_s;
 	const int s = blockIdx.x;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
+	uint32_t *rs = re + (a.in_stride >> 2);
+	uint32_t *rl = re + (a.in_stride >> 1);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) s_base = 0;
+	if (threadIdx.x == 0) { s_base_e = 0; s_base_s = 0; }
 	__syncthreads();
-	for (uint32_t x0 = 0; x0 < L; x0 += blockDim.x) {
-		const uint32_t x = x0 + threadIdx.x;
-		const bool flag = x >= 3 && x < L && in[x - 1] == in[x - 2] && in[x - 2] == in[x - 3] && in[x] != in[x - 1];
-		const uint64_t bal = __ballot(flag);
-		if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+	for (uint32_t x0 = 0; x0 < L; x0 += blockDim.x * 4) {
+		const uint32_t x = x0 + threadIdx.x * 4;
+		// bytes in[x-3 .. x+5], kept as c[0..8]
+		uint8_t c[9];
+#pragma unroll
+		for (int k = 0; k < 9; k++) { const int64_t y = (int64_t)x - 3 + k; c[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
+		uint32_t me = 0, ms = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t y = x + k;  // c[k + 3] = in[y]
+			const bool e = y >= 3 && y < L && c[k + 2] == c[k + 1] && c[k + 1] == c[k] && c[k + 3] != c[k + 2];
+			const bool st = y + 2 < L && c[k + 4] == c[k + 3] && c[k + 5] == c[k + 3] && (y == 0 || c[k + 2] != c[k + 3]);
+			me |= (uint32_t)e << k; ms |= (uint32_t)st << k;
+		}
+		const uint32_t cnt = (uint32_t)__popc(me) | ((uint32_t)__popc(ms) << 16);
+		uint32_t inc = cnt;  // inclusive wave scan of both counters at once
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+		if (lane == 63) wsum[wave] = inc;
 		__syncthreads();
 		uint32_t wb = 0, tot = 0;
 		for (int w = 0; w < 4; w++) { if (w < wave) wb += wsum[w]; tot += wsum[w]; }
-		const uint32_t base = s_base;
-		if (flag) re[base + wb + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = x;
+		const uint32_t excl = wb + inc - cnt;
+		uint32_t ie = s_base_e + (excl & 0xFFFFu), is = s_base_s + (excl >> 16);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if ((me >> k) & 1u) re[ie++] = x + k;
+			if ((ms >> k) & 1u) rs[is++] = x + k;
+		}
 		__syncthreads();
-		if (threadIdx.x == 0) s_base = base + tot;
+		if (threadIdx.x == 0) { s_base_e += tot & 0xFFFFu; s_base_s += tot >> 16; }
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) a.run_end_count[s] = s_base;
+	const uint32_t nre = s_base_e;
+	for (uint32_t t = threadIdx.x; t < nre; t += blockDim.x) {
+		const uint32_t x = re[t], len = x - rs[t];
+		rl[t] = (len < 511u ? len : 511u) | ((uint32_t)in[x - 1] << 16);
+	}
+	if (threadIdx.x == 0) a.run_end_count[s] = nre;
 }
 
-__global__ void __launch_bounds__(256) dfl_match_deep_kernel(DeflateArgs a)
+// Positions p whose string starts with three equal bytes b (r = number of b's from p, capped).
+// Every candidate of that bucket that can reach length 3 is itself a position of some run of b:
+//   * p-1 (when in[p-1] == b) is the chain head and yields exactly r;
+//   * a position q of an EARLIER run [s_j, e_j) yields min(e_j - q, r), plus the common prefix of what
+//     follows both runs when e_j - q == r; descending q inside a run, the first position reaching the run's
+//     maximum is q = e_j - r (run long enough) or the lowest position still inside the chain limits.
+// So the lane scans run ends backwards, one O(1) step per run.  The limits of deflate.c become position
+// limits: the first K chain entries are the sorted indices i-1 .. i-K (K = 4096, and 1024 for the
+// good_match variant); distance < MAX_DIST; position 0 is NIL.
+__global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a)
 {
 	const int s = blockIdx.y;
 	const uint32_t L = a.in_sizes[s];
@@ -272,6 +324,7 @@ __global__ void __launch_bounds__(256) dfl_match_deep_kernel(DeflateArgs a)
 	const uint32_t *deep = a.heavy_list + base + a.in_stride - 1;  // grows downwards from the end
 	const uint32_t ndeep = a.deep_count[s];
 	const uint32_t *re = a.run_ends + base;
+	const uint32_t *rl = re + (a.in_stride >> 1);
 	const uint32_t nre = a.run_end_count[s];
 	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ndeep; e += gridDim.x * blockDim.x) {
 		const uint32_t i = *(deep - e);
@@ -280,41 +333,55 @@ __global__ void __launch_bounds__(256) dfl_match_deep_kernel(DeflateArgs a)
 		const uint32_t lookahead = L - p;
 		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
 		const uint8_t b = in[p];
-		uint32_t r = 3;
-		while (r < max_len && in[p + r] == b) r++;
-		uint32_t best4 = r, q4 = p - 1, best1 = r, q1 = p - 1;
-		if (r < max_len) {  // (r == max_len never reaches this kernel: the light pass ends at the chain head)
-			const uint8_t c = in[p + r];
+		const uint32_t r = mr[p].x >> 16;  // run length from p, capped at max_len (left by dfl_match_kernel)
+		const bool has_prev = p >= 2 && in[p - 1] == b;  // position 0 is NIL
+		uint32_t best4 = has_prev ? r : 0u, q4 = p - 1, best1 = best4, q1 = p - 1;
+		bool scan = true;
+		if (!has_prev) {  // chain head rules of deflate_slow / longest_match
+			const bool have_head = i >= 1 && keys[i - 1] == h;
+			const uint32_t hq = have_head ? vals[i - 1] : 0u;
+			if (!have_head || hq == 0 || hq == nil_candidate(p, lookahead) || p - hq > (uint32_t)MAX_DIST) scan = false;
+			else if (p - hq == (uint32_t)MAX_DIST) {  // only the head itself may sit at distance MAX_DIST
+				uint32_t len = 0;
+				while (len < max_len && in[hq + len] == in[p + len]) len++;
+				best4 = best1 = len; q4 = q1 = hq;
+				scan = false;
+			}
+		}
+		if (scan && best4 < max_len) {
+			const bool ext_ok = r < max_len;  // bytes after the run can only matter below the cap
+			const uint8_t c = ext_ok ? in[p + r] : 0;
 			const uint32_t qw = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1 : 1u;  // dist < MAX_DIST, q != NIL
 			uint32_t qmin4 = qw, qmin1 = qw;
 			if (i >= 4096 && keys[i - 4096] == h) qmin4 = max(qmin4, vals[i - 4096]);
 			if (i >= 1024 && keys[i - 1024] == h) qmin1 = max(qmin1, vals[i - 1024]);
-			// start of p's own run, then the last run end at or before it
-			uint32_t sp = p;
-			while (sp > 0 && in[sp - 1] == b && p - sp < 300) sp--;
-			if (sp > 0 && in[sp - 1] == b) {  // very long run: its start is further than any useful candidate
-				uint32_t lo = 0, hi = nre;   // binary search instead: last run end <= p
-				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
-				sp = lo ? re[lo - 1] : 0;     // (run ends inside p's run do not exist, so this is <= run start)
-			}
-			uint32_t lo = 0, hi = nre;
-			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= sp) lo = mid + 1; else hi = mid; }
+			uint32_t lo = 0, hi = nre;  // last run end <= p (none lies strictly inside p's own run)
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
 				const uint32_t x = re[t];
-				if (x < qmin4 + r) break;  // q = x - r would fall outside the first 4096 chain entries / the window
-				if (in[x - 1] != b || in[x] != c) continue;
-				uint32_t run = 3;
-				while (run < r && x >= run + 1 && in[x - 1 - run] == b) run++;
-				if (run < r) continue;        // the earlier run is shorter than what p needs
-				const uint32_t q = x - r;
-				uint32_t len = r + 1;
-				while (len < max_len && in[q + len] == in[p + len]) len++;
-				if (len > best4) { best4 = len; q4 = q; }
-				if (q >= qmin1 && len > best1) { best1 = len; q1 = q; }
-				if (best4 >= max_len) break;
+				if (x < qmin4 + 3) break;          // even q = x-3 is outside the first 4096 entries / the window
+				const uint32_t lw = rl[t];         // min(run length, 511) | run byte << 16
+				if ((lw >> 16) != b) continue;     // a run of another byte
+				const uint32_t m = min(min(lw & 0xFFFFu, r), x - qmin4);  // run length counted down to qmin4, capped at r
+				if (m >= 3) {
+					uint32_t q, len;
+					if (m == r) {
+						q = x - r; len = r;
+						if (ext_ok && in[x] == c) { len = r + 1; while (len < max_len && in[q + len] == in[p + len]) len++; }
+					} else { q = x - m; len = m; }
+					if (len > best4) { best4 = len; q4 = q; }
+					// the same run seen through the 1024-entry limit
+					if (x >= qmin1 + 3) {
+						const uint32_t m1 = min(m, x - qmin1);
+						if (m1 == m) { if (len > best1) { best1 = len; q1 = q; } }
+						else if (m1 >= 3 && m1 > best1) { best1 = m1; q1 = x - m1; }
+					}
+					if (best4 >= max_len) break;
+				}
+				if (x - m <= qmin4) break;  // the run was cut by the limit: older runs are outside
 			}
 		}
-		mr[p] = make_uint2(best4 | (best1 << 16), (p - q4) | ((p - q1) << 16));
+		mr[p] = make_uint2(best4 | (best1 << 16), (best4 ? p - q4 : 0u) | ((best1 ? p - q1 : 0u) << 16));
 	}
 }
 
@@ -473,9 +540,13 @@ struct TreeScratch {  // one block's working set, in LDS
 	uint16_t freq[HEAP_SIZE], dad[HEAP_SIZE], len[HEAP_SIZE], code[HEAP_SIZE];        // literal/length tree
 	uint16_t dfreq[2 * D_CODES + 1], ddad[2 * D_CODES + 1], dlen[2 * D_CODES + 1], dcode[2 * D_CODES + 1];
 	uint16_t bfreq[2 * BL_CODES + 1], bdad[2 * BL_CODES + 1], blen[2 * BL_CODES + 1], bcode[2 * BL_CODES + 1];
-	uint16_t heap[HEAP_SIZE];
+	// heap entries carry their own sort key: freq << 15 | depth << 10 | node, so that trees.c's smaller(n, m)
+	// is (e_n >> 10) <= (e_m >> 10) and one 64-bit LDS read fetches both children (freq <= 16384: 15 bits;
+	// depth <= 21 for that total weight: 5 bits; node < 573: 10 bits)
+	alignas(8) uint32_t heap[HEAP_SIZE + 1];
 	uint8_t depth[HEAP_SIZE];
 	uint16_t bl_count[MAX_BITS + 1];
+	uint16_t next_code[MAX_BITS + 1];
 	int heap_len, heap_max;
 	uint32_t opt_len, static_len;
 	uint32_t hdr_bits[160];  // dynamic-block header: 14 + 3*19 + up to 316 * 14 bits
@@ -484,30 +555,26 @@ struct TreeScratch {  // one block's working set, in LDS
 
 struct TreeView { uint16_t *freq, *dad, *len, *code; };
 
-__device__ __forceinline__ bool smaller(const TreeView &t, const uint8_t *depth, int n, int m)
+__device__ __forceinline__ uint32_t heap_entry(const TreeView &t, const uint8_t *depth, int n)
 {
-	return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && depth[n] <= depth[m]);
+	return ((uint32_t)t.freq[n] << 15) | ((uint32_t)depth[n] << 10) | (uint32_t)n;
 }
 
-__device__ void pqdownheap(TreeScratch &S, const TreeView &t, int k)
+__device__ __forceinline__ void pqdownheap(TreeScratch &S, int k)
 {
-	const int v = S.heap[k];
+	const uint32_t v = S.heap[k];
+	const int hl = S.heap_len;
 	int j = k << 1;
-	while (j <= S.heap_len) {
-		if (j < S.heap_len && smaller(t, S.depth, S.heap[j + 1], S.heap[j])) j++;
-		if (smaller(t, S.depth, v, S.heap[j])) break;
-		S.heap[k] = S.heap[j];
+	while (j <= hl) {
+		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[j]);  // j is even: children j, j+1 in one read
+		uint32_t e = pr.x;
+		if (j < hl && (pr.y >> 10) <= (pr.x >> 10)) { j++; e = pr.y; }
+		if ((v >> 10) <= (e >> 10)) break;
+		S.heap[k] = e;
 		k = j;
 		j <<= 1;
 	}
-	S.heap[k] = (uint16_t)v;
-}
-
-__device__ uint32_t bi_reverse(uint32_t code, int len)
-{
-	uint32_t res = 0;
-	do { res |= code & 1; code >>= 1; res <<= 1; } while (--len > 0);
-	return res >> 1;
+	S.heap[k] = v;
 }
 
 // build_tree + gen_bitlen + gen_codes (trees.c:486-700).  kind: 0 literal/length, 1 distance, 2 bit-length
@@ -519,34 +586,41 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 	int n, m, max_code = -1, node;
 	S.heap_len = 0; S.heap_max = HEAP_SIZE;
 	for (n = 0; n < elems; n++) {
-		if (t.freq[n] != 0) { S.heap[++S.heap_len] = (uint16_t)(max_code = n); S.depth[n] = 0; }
+		if (t.freq[n] != 0) { S.depth[n] = 0; S.heap[++S.heap_len] = heap_entry(t, S.depth, max_code = n); }
 		else t.len[n] = 0;
 	}
 	while (S.heap_len < 2) {
-		node = S.heap[++S.heap_len] = (uint16_t)(max_code < 2 ? ++max_code : 0);
+		node = max_code < 2 ? ++max_code : 0;
 		t.freq[node] = 1; S.depth[node] = 0; S.opt_len--;
+		S.heap[++S.heap_len] = heap_entry(t, S.depth, node);
 		if (kind == 0) S.static_len -= c_static_llen[node];
 		else if (kind == 1) S.static_len -= 5;
 	}
-	for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, t, n);
+	for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, n);
 	node = elems;
 	do {
-		n = S.heap[1]; S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, t, 1);
-		m = S.heap[1];
-		S.heap[--S.heap_max] = (uint16_t)n; S.heap[--S.heap_max] = (uint16_t)m;
-		t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
-		S.depth[node] = (uint8_t)((S.depth[n] >= S.depth[m] ? S.depth[n] : S.depth[m]) + 1);
+		const uint32_t en = S.heap[1];
+		S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, 1);
+		const uint32_t em = S.heap[1];
+		n = (int)(en & 1023u); m = (int)(em & 1023u);
+		S.heap[--S.heap_max] = en; S.heap[--S.heap_max] = em;
+		const uint32_t f = (en >> 15) + (em >> 15);
+		const uint32_t dn = (en >> 10) & 31u, dm = (em >> 10) & 31u;
+		const uint32_t d = (dn >= dm ? dn : dm) + 1;
+		t.freq[node] = (uint16_t)f;
+		S.depth[node] = (uint8_t)d;
 		t.dad[n] = t.dad[m] = (uint16_t)node;
-		S.heap[1] = (uint16_t)node++;
-		pqdownheap(S, t, 1);
+		S.heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
+		node++;
+		pqdownheap(S, 1);
 	} while (S.heap_len >= 2);
 	S.heap[--S.heap_max] = S.heap[1];
 	// gen_bitlen
 	int h, bits, overflow = 0;
 	for (bits = 0; bits <= MAX_BITS; bits++) S.bl_count[bits] = 0;
-	t.len[S.heap[S.heap_max]] = 0;
+	t.len[S.heap[S.heap_max] & 1023u] = 0;
 	for (h = S.heap_max + 1; h < HEAP_SIZE; h++) {
-		n = S.heap[h];
+		n = (int)(S.heap[h] & 1023u);
 		bits = t.len[t.dad[n]] + 1;
 		if (bits > max_length) { bits = max_length; overflow++; }
 		t.len[n] = (uint16_t)bits;
@@ -569,7 +643,7 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 		for (bits = max_length; bits != 0; bits--) {
 			n = S.bl_count[bits];
 			while (n != 0) {
-				m = S.heap[--h];
+				m = (int)(S.heap[--h] & 1023u);
 				if (m > max_code) continue;
 				if ((uint32_t)t.len[m] != (uint32_t)bits) {
 					S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
@@ -580,13 +654,12 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 		}
 	}
 	// gen_codes
-	uint16_t next_code[MAX_BITS + 1];
 	uint32_t code = 0;
-	for (bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; next_code[bits] = (uint16_t)code; }
+	for (bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; S.next_code[bits] = (uint16_t)code; }
 	for (n = 0; n <= max_code; n++) {
 		const int len = t.len[n];
 		if (len == 0) continue;
-		t.code[n] = (uint16_t)bi_reverse(next_code[len]++, len);
+		t.code[n] = (uint16_t)(__brev((uint32_t)S.next_code[len]++) >> (32 - len));
 	}
 	return max_code;
 }
@@ -1009,10 +1082,10 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	if ((e = rocprim::segmented_radix_sort_pairs(sort_temp, tb, a.keys_in, a.keys_out, a.vals_in, a.vals_out,
 	                                             (unsigned int)total, (unsigned int)n, a.seg_begin, a.seg_end, 0, 15, st)) != hipSuccess)
 		return e;
+	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_match_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_match_deep_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);

@@ -131,6 +131,114 @@ static void find_matches(const uint8_t *in, int64_t L, const int32_t *prevq, int
 	r->len4096 = (uint16_t)best; r->dist4096 = (uint16_t)(best ? p - best_q : 0);
 }
 
+/* ------------------------------------------------------------------ run rule (checker for dfl_match_run_kernel)
+ * For a position whose string starts with three equal bytes the device does not walk the hash chain: it
+ * derives the same record from the list of run ends.  This restates that rule on the CPU so that the not-gpu
+ * tests can compare it with find_matches() on every such position.
+ * spos[] = positions sorted by (hash, position), sidx[p] = index of p in spos, skey[i] = hash of spos[i]. */
+static void run_rule(const uint8_t *in, int64_t L, const int32_t *spos, const uint16_t *skey, const int32_t *sidx,
+                     const int32_t *re, int32_t nre, int64_t p, match_rec *out)
+{
+	const int64_t i = sidx[p];
+	const unsigned h = skey[i];
+	const int64_t lookahead = L - p;
+	const int64_t max_len = lookahead < MAX_MATCH ? lookahead : MAX_MATCH;
+	const uint8_t b = in[p];
+	int64_t r = 3;
+	while (r < max_len && in[p + r] == b) r++;
+	const int has_prev = p >= 2 && in[p - 1] == b;  /* position 0 is NIL */
+	int64_t best4 = has_prev ? r : 0, q4 = p - 1, best1 = best4, q1 = p - 1;
+	int scan = 1;
+	const int64_t nil_q = (L - p < MIN_LOOKAHEAD && p >= 32506 + 32768 && (p - 32506) % 32768 == 0) ? p - 32506 : -2;
+	if (!has_prev) {
+		const int have_head = i >= 1 && skey[i - 1] == h;
+		const int64_t hq = have_head ? spos[i - 1] : 0;
+		if (!have_head || hq == 0 || hq == nil_q || p - hq > MAX_DIST) scan = 0;
+		else if (p - hq == MAX_DIST) {
+			int64_t len = 0;
+			while (len < max_len && in[hq + len] == in[p + len]) len++;
+			best4 = best1 = len; q4 = q1 = hq; scan = 0;
+		}
+	}
+	if (scan && best4 < max_len) {
+		const int ext_ok = r < max_len;
+		const uint8_t c = ext_ok ? in[p + r] : 0;
+		const int64_t qw = p >= MAX_DIST ? p - MAX_DIST + 1 : 1;
+		int64_t qmin4 = qw, qmin1 = qw;
+		if (i >= 4096 && skey[i - 4096] == h && spos[i - 4096] > qmin4) qmin4 = spos[i - 4096];
+		if (i >= 1024 && skey[i - 1024] == h && spos[i - 1024] > qmin1) qmin1 = spos[i - 1024];
+		int32_t lo = 0, hi = nre;
+		while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
+		for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
+			const int64_t x = re[t];
+			if (x < qmin4 + 3) break;
+			if (in[x - 1] != b) continue;
+			int64_t m = 0;
+			while (m < r && x - 1 - m >= qmin4 && in[x - 1 - m] == b) m++;
+			if (m >= 3) {
+				int64_t q, len;
+				if (m == r) {
+					q = x - r; len = r;
+					if (ext_ok && in[x] == c) { len = r + 1; while (len < max_len && in[q + len] == in[p + len]) len++; }
+				} else { q = x - m; len = m; }
+				if (len > best4) { best4 = len; q4 = q; }
+				if (x >= qmin1 + 3) {
+					const int64_t m1 = m < x - qmin1 ? m : x - qmin1;
+					if (m1 == m) { if (len > best1) { best1 = len; q1 = q; } }
+					else if (m1 >= 3 && m1 > best1) { best1 = m1; q1 = x - m1; }
+				}
+				if (best4 >= max_len) break;
+			}
+			if (m < r && x - 1 - m < qmin4) break;
+		}
+	}
+	out->len4096 = (uint16_t)best4; out->len1024 = (uint16_t)best1;
+	out->dist4096 = (uint16_t)(best4 ? p - q4 : 0); out->dist1024 = (uint16_t)(best1 ? p - q1 : 0);
+}
+
+/* Returns -1 when the run rule agrees with the chain walk on every run position, else the first position that
+ * differs.  Lengths below MIN_MATCH are equivalent (deflate_slow ignores them). */
+int64_t cct_model_check_run_rule(const uint8_t *in, size_t len)
+{
+	const int64_t L = (int64_t)len;
+	if (L < MIN_MATCH) return -1;
+	const int64_t npos = L - 2;
+	int32_t *prevq = (int32_t *)malloc((size_t)(L + 1) * sizeof(int32_t));
+	int32_t *head = (int32_t *)malloc(32768 * sizeof(int32_t));
+	int32_t *cnt = (int32_t *)calloc(32769, sizeof(int32_t));
+	int32_t *spos = (int32_t *)malloc((size_t)npos * sizeof(int32_t));
+	uint16_t *skey = (uint16_t *)malloc((size_t)npos * sizeof(uint16_t));
+	int32_t *sidx = (int32_t *)malloc((size_t)npos * sizeof(int32_t));
+	int32_t *re = (int32_t *)malloc((size_t)(L + 1) * sizeof(int32_t));
+	for (int i = 0; i < 32768; i++) head[i] = -1;
+	for (int64_t p = 0; p < npos; p++) {
+		const unsigned h = (((unsigned)in[p] << 10) ^ ((unsigned)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFF;
+		prevq[p] = head[h]; head[h] = (int32_t)p; cnt[h + 1]++;
+	}
+	for (int i = 0; i < 32768; i++) cnt[i + 1] += cnt[i];
+	for (int64_t p = 0; p < npos; p++) {
+		const unsigned h = (((unsigned)in[p] << 10) ^ ((unsigned)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFF;
+		const int32_t i = cnt[h]++;
+		spos[i] = (int32_t)p; skey[i] = (uint16_t)h; sidx[p] = i;
+	}
+	int32_t nre = 0;
+	for (int64_t x = 3; x < L; x++)
+		if (in[x - 1] == in[x - 2] && in[x - 2] == in[x - 3] && in[x] != in[x - 1]) re[nre++] = (int32_t)x;
+	int64_t bad = -1;
+	for (int64_t p = 0; p < npos && bad < 0; p++) {
+		if (!(in[p + 1] == in[p] && in[p + 2] == in[p])) continue;
+		match_rec a, b;
+		find_matches(in, L, prevq, p, &a);
+		run_rule(in, L, spos, skey, sidx, re, nre, p, &b);
+		const int a4 = a.len4096 >= MIN_MATCH, b4 = b.len4096 >= MIN_MATCH, a1 = a.len1024 >= MIN_MATCH, b1 = b.len1024 >= MIN_MATCH;
+		if (a4 != b4 || a1 != b1) bad = p;
+		else if (a4 && (a.len4096 != b.len4096 || a.dist4096 != b.dist4096)) bad = p;
+		else if (a1 && (a.len1024 != b.len1024 || a.dist1024 != b.dist1024)) bad = p;
+	}
+	free(prevq); free(head); free(cnt); free(spos); free(skey); free(sidx); free(re);
+	return bad;
+}
+
 /* ------------------------------------------------------------------ bit writer */
 
 typedef struct { uint8_t *out; size_t pos; uint32_t bi_buf; int bi_valid; } bitw;

@@ -63,3 +63,74 @@ def test_real_slice_payload_reproduces_reference_file(model):
     with open(os.path.join(gi.GOLDEN, "slice0671.cct"), "rb") as f:
         ref = f.read()
     assert model(payload) == ref[13:]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# run rule: the device evaluates positions that start a run of three equal bytes from the list of run ends
+# (dfl_match_run_kernel) instead of walking the hash chain.  cct_model_check_run_rule restates that rule on
+# the CPU and compares it with the chain walk (= deflate.c longest_match) on every such position.
+@pytest.fixture(scope="module")
+def run_rule():
+    subprocess.check_call(["make", "-s", "-C", ODIR, "libdeflate_model.so"])
+    L = C.CDLL(os.path.join(ODIR, "libdeflate_model.so"))
+    L.cct_model_check_run_rule.restype = C.c_int64
+    L.cct_model_check_run_rule.argtypes = [C.c_char_p, C.c_size_t]
+    return lambda b: L.cct_model_check_run_rule(b, len(b))
+
+
+def _short_runs(rng, n):
+    parts, tot = [], 0
+    lo, hi = [(3, 6), (3, 40), (200, 300), (3, 600)][int(rng.integers(0, 4))]
+    while tot < n:
+        k = int(rng.integers(lo, hi))
+        sep = bytes(rng.integers(1, 3 + int(rng.integers(0, 3)), int(rng.integers(1, 3)), dtype=np.uint8))
+        parts += [bytes(k), sep]
+        tot += k + len(sep)
+    return b"".join(parts)[:n]
+
+
+def _colliding(rng, n):
+    # (32,0,0) and (1,32,0) hash to the bucket of (0,0,0)
+    parts, tot = [], 0
+    while tot < n:
+        c = rng.random()
+        if c < 0.4:
+            parts.append(bytes(int(rng.integers(3, 50))))
+        elif c < 0.6:
+            parts.append(bytes([32, 0, 0]))
+        elif c < 0.8:
+            parts.append(bytes([1, 32, 0]))
+        else:
+            parts.append(bytes(rng.integers(0, 40, int(rng.integers(1, 4)), dtype=np.uint8)))
+        tot += len(parts[-1])
+    return b"".join(parts)[:n]
+
+
+def _far_runs(rng, n):
+    # runs spaced around MAX_DIST (32506) and the window size
+    parts, tot = [], 0
+    while tot < n:
+        k = int(rng.integers(3, 300))
+        gap = max(1, int(rng.choice([32506 - k, 32505 - k, 32507 - k, 32768 - k, 100, 1000, 16000, 32506, 32503])))
+        parts += [bytes([int(rng.integers(0, 2))]) * k, bytes(rng.integers(2, 256, gap, dtype=np.uint8))]
+        tot += k + gap
+    return b"".join(parts)[:n]
+
+
+@pytest.mark.parametrize("data", [bytes(10), b"\1" + bytes(12), bytes(4) + b"\1" + bytes(5) + b"\2", bytes(258), bytes(259),
+                                  bytes(3), bytes(70000), b"ab" + b"c" * 300 + b"ab" + b"c" * 300 + b"d" + b"c" * 299 + b"d"])
+def test_run_rule_small_cases(run_rule, data):
+    assert run_rule(data) == -1
+
+
+@pytest.mark.parametrize("gen", [_short_runs, _colliding, _far_runs])
+@pytest.mark.parametrize("seed", range(6))
+def test_run_rule_adversarial(run_rule, gen, seed):
+    rng = np.random.default_rng(1000 + seed)
+    assert run_rule(gen(rng, int(rng.integers(1000, 200000)))) == -1
+
+
+@pytest.mark.parametrize("name", ["slice0671", "slice3706"])
+def test_run_rule_real_payloads(run_rule, name):
+    payload = oracle.encode(gi.load_slice(name), deflate=False)[13:]
+    assert run_rule(payload) == -1
