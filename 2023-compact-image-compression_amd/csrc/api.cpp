@@ -415,6 +415,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n;
 	a.mr = g_ctx.z_mr.p; a.heavy_list = (uint32_t *)g_ctx.z_rec.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
 	a.run_ends = (uint32_t *)g_ctx.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
+	a.run_len = (uint16_t *)g_ctx.z_keys_in.p;
 	a.rec32 = (uint32_t *)g_ctx.z_exitp.p; a.exit_pos = (uint32_t *)g_ctx.z_exitc.p; a.exit_cnt = (uint32_t *)g_ctx.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
 	a.blk_entry = (uint32_t *)g_ctx.z_bentry.p; a.blk_symbase = (uint32_t *)g_ctx.z_bsym.p;
 	a.blk_end = (uint32_t *)g_ctx.z_bend.p;
@@ -432,7 +433,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 		b.keys_in += eo; b.keys_out += eo; b.vals_in += eo; b.vals_out += eo;
 		b.seg_begin += s0; b.seg_end += s0; b.total_syms += s0; b.postloop_lit += s0; b.n_blocks += s0; b.adler += s0;
 		b.heavy_count += s0; b.deep_count += s0; b.run_end_count += s0;
-		b.mr = (uint8_t *)b.mr + eo * 8; b.heavy_list += eo; b.sym += eo; b.run_ends += eo;
+		b.mr = (uint8_t *)b.mr + eo * 8; b.heavy_list += eo; b.sym += eo; b.run_ends += eo; b.run_len += eo;
 		b.rec32 += eo; b.exit_pos += eo; b.exit_cnt += eo;
 		b.blk_entry += bo; b.blk_symbase += bo;
 		b.blk_end += mo; b.block_meta += mo; b.block_tables += mo;

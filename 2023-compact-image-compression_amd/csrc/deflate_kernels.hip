@@ -79,31 +79,118 @@ __global__ void dfl_hash_kernel(DeflateArgs a)
 // Pass B: one WAVE per heavy position, 64 candidates per step.
 constexpr int LIGHT_STEPS = 12;
 
+// Block -> (slice, part) for the kernels that touch one slice's arrays at random (hash order): match records
+// are scattered 8-byte stores and the string loads are scattered too, so they only stay on chip if the whole
+// working set of a slice (~3 MB) sits in ONE L2 while it is being processed.  Blocks are dealt round-robin
+// over the 8 XCDs (observed behaviour, used for speed only): blocks lin and lin + 8 share an L2, so the blocks
+// with lin % 8 == c walk through slices c, c + 8, c + 16, ... one after the other.  gridDim.y is n rounded up to 8.
+__device__ __forceinline__ bool xcd_slice(int n, int &s, uint32_t &part, uint32_t &nparts)
+{
+	const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
+	const uint32_t c = lin & 7u, k = lin >> 3;
+	nparts = gridDim.x;
+	s = (int)(8u * (k / nparts) + c);
+	part = k % nparts;
+	return s < n;
+}
+
 __device__ __forceinline__ uint32_t nil_candidate(uint32_t p, uint32_t lookahead)
 {
 	// slide_hash NIL quirk at the very end of the input (see oracle/deflate_model.c)
 	return (lookahead < (uint32_t)MIN_LOOKAHEAD && p >= 32506u + 32768u && (p - 32506u) % 32768u == 0) ? p - 32506u : 0xFFFFFFFFu;
 }
 
-// number of bytes equal to sp[0] starting at sp, capped at cap (<= bytes available); 8 bytes per step
-__device__ __forceinline__ uint32_t run_ahead(const uint8_t *sp, uint32_t cap)
+// ------------------------------------------------------------------ 1b. run length ahead of every position
+// run_len[p] = number of bytes equal to in[p] starting at p, capped at MAX_MATCH (and by the end of the input),
+// with bit 15 = (p >= 2 && in[p-1] == in[p]).  The match kernels visit positions in hash order, where
+// scanning the bytes would be a chain of uncoalesced loads; here the input is read once, in order.
+// A workgroup scans 2048 positions (8 per lane) and publishes the first RUNLEN_OUT of them: for those the
+// scanned tail (>= 264 bytes) decides every length below the cap.
+constexpr int RUNLEN_OUT = 2048 - 264;
+
+__global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 {
-	const uint64_t pat = 0x0101010101010101ull * sp[0];
-	uint32_t r = 0;
-	while (r + 8 <= cap) {
-		uint64_t w;
-		__builtin_memcpy(&w, sp + r, 8);
-		const uint64_t d = w ^ pat;
-		if (d) return r + ((uint32_t)__ffsll((long long)d) - 1u) / 8u;
-		r += 8;
+	__shared__ uint32_t wtot[4];  // per wave: has_change << 31 | distance from the wave's first position to its first change
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	uint16_t *rl = a.run_len + (size_t)s * a.in_stride;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t nchunks = (L + RUNLEN_OUT - 1) / RUNLEN_OUT;
+	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+		const uint32_t c0 = c * RUNLEN_OUT;
+		const uint32_t g = c0 + threadIdx.x * 8;  // first of this lane's 8 positions
+		uint8_t b[10];                            // in[g-1 .. g+8]
+		if (g + 9 <= L && g >= 1) {
+			uint64_t w;
+			__builtin_memcpy(&w, in + g, 8);
+#pragma unroll
+			for (int k = 0; k < 8; k++) b[k + 1] = (uint8_t)(w >> (8 * k));
+			b[0] = in[g - 1]; b[9] = in[g + 8];
+		} else {
+#pragma unroll
+			for (int k = 0; k < 10; k++) { const int64_t y = (int64_t)g - 1 + k; b[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
+		}
+		uint32_t chg = 0;  // bit k: the run containing position g+k ends at g+k
+#pragma unroll
+		for (int k = 0; k < 8; k++) chg |= (uint32_t)(b[k + 1] != b[k + 2] || g + k + 1 >= L) << k;
+		// suffix scan over lanes of (has_change, distance to first change): spans combine as
+		//   (cA, nA) . (cB, nB) = (cA | cB, cA ? nA : nA + nB)       with n = 8 * span for a change-free span
+		uint32_t hc = chg != 0, n = hc ? (uint32_t)__ffs((int)chg) - 1u : 8u;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t hb = (uint32_t)__shfl_down((int)hc, d, 64), nb = (uint32_t)__shfl_down((int)n, d, 64);
+			if (lane + d < 64 && !hc) { n += nb; hc = hb; }
+		}
+		__syncthreads();  // wtot of the previous chunk has been read by everyone
+		if (lane == 0) wtot[wave] = (hc << 31) | n;
+		__syncthreads();
+		uint32_t xh = 0, xn = 0;  // the waves after this one
+		for (int w = 3; w > wave; w--) {
+			const uint32_t t = wtot[w];
+			if (t >> 31) { xh = 1; xn = t & 0x7FFFFFFFu; } else xn += t & 0x7FFFFFFFu;
+		}
+		if (!xh) xn += 1024;  // nothing scanned beyond: only reached by positions that are not published
+		const uint32_t nfull = hc ? n : n + xn;  // distance from g to the first change at or after g
+		uint32_t nnext = (uint32_t)__shfl_down((int)nfull, 1, 64);  // the same for g + 8
+		if (lane == 63) nnext = xn;
+		uint16_t out[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const uint32_t rest = chg >> k;
+			uint32_t r = rest ? (uint32_t)__ffs((int)rest) : (8u - k) + nnext + 1u;
+			if (r > (uint32_t)MAX_MATCH) r = MAX_MATCH;
+			out[k] = (uint16_t)(r | ((g + k >= 2 && b[k] == b[k + 1]) ? 0x8000u : 0u));
+		}
+		if (threadIdx.x * 8 < (uint32_t)RUNLEN_OUT && g < L) {
+			if (g + 8 <= L && threadIdx.x * 8 + 8 <= (uint32_t)RUNLEN_OUT) __builtin_memcpy(rl + g, out, 16);
+			else {
+#pragma unroll
+				for (int k = 0; k < 8; k++) if (g + k < L && threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT) rl[g + k] = out[k];
+			}
+		}
 	}
-	while (r < cap && sp[r] == sp[0]) r++;
-	return r;
 }
 
-__global__ void dfl_match_kernel(DeflateArgs a)
+// length of the common prefix of x and y, continuing from len, capped at cap; 8 bytes per step
+__device__ __forceinline__ int common_prefix(const uint8_t *x, const uint8_t *y, int len, int cap)
 {
-	const int s = blockIdx.y;
+	while (len + 8 <= cap) {
+		uint64_t u, v;
+		__builtin_memcpy(&u, x + len, 8);
+		__builtin_memcpy(&v, y + len, 8);
+		const uint64_t d = u ^ v;
+		if (d) return len + ((__ffsll((long long)d) - 1) >> 3);
+		len += 8;
+	}
+	while (len < cap && x[len] == y[len]) len++;
+	return len;
+}
+
+__global__ void dfl_match_kernel(DeflateArgs a, int n)
+{
+	int s; uint32_t part, nparts;
+	if (!xcd_slice(n, s, part, nparts)) return;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
@@ -112,61 +199,76 @@ __global__ void dfl_match_kernel(DeflateArgs a)
 	const uint32_t *vals = a.vals_out + base;
 	MatchRec *mr = reinterpret_cast<MatchRec *>(a.mr) + base;
 	uint32_t *heavy = a.heavy_list + base;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npos; i += gridDim.x * blockDim.x) {
-		const uint32_t p = vals[i];
-		const uint32_t h = keys[i];
-		const uint32_t lookahead = L - p;
-		const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
-		const uint32_t nil_q = nil_candidate(p, lookahead);
-		int best = 0, count = 0;
-		uint32_t best_q = 0;
-		const uint8_t *sp = in + p;
-		bool done = true;
-		// strings that START a run of three equal bytes share one bucket with every other position of
-		// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
-		// the list of run ends instead of walking the chain
-		const bool in_run = max_len >= 3 && sp[1] == sp[0] && sp[2] == sp[0];
-		if (in_run) {
-			const int r = (int)run_ahead(sp, (uint32_t)max_len);
-			if (p >= 2 && sp[-1] == sp[0] && r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
-			else {
-				MatchRec rr;  // sentinel; len1024 hands the run length to dfl_match_run_kernel
-				rr.len4096 = 0xFFFF; rr.len1024 = (uint16_t)r; rr.dist4096 = (uint16_t)(i & 0xFFFFu); rr.dist1024 = (uint16_t)(i >> 16);
-				mr[p] = rr;
-				*(heavy + a.in_stride - 1 - atomicAdd(&a.deep_count[s], 1u)) = i;
-				continue;
+	const uint16_t *rl = a.run_len + base;
+	const int lane = threadIdx.x & 63;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+	for (uint32_t i0 = part * blockDim.x; i0 < npos; i0 += nparts * blockDim.x) {  // wave-uniform trip count
+		const uint32_t i = i0 + threadIdx.x;
+		int kind = 0;  // 0: record written, 1: queue for the cooperative heavy pass, 2: queue for the run pass
+		if (i < npos) {
+			const uint32_t p = vals[i];
+			const uint32_t h = keys[i];
+			const uint32_t lookahead = L - p;
+			const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
+			const uint32_t nil_q = nil_candidate(p, lookahead);
+			int best = 0, count = 0;
+			uint32_t best_q = 0;
+			const uint8_t *sp = in + p;
+			// strings that START a run of three equal bytes share one bucket with every other position of
+			// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
+			// the list of run ends instead of walking the chain
+			const uint32_t rw = rl[p];
+			const uint32_t run_r = rw & 0x7FFFu;  // <= max_len by construction
+			if (run_r >= 3) {
+				if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
+				else kind = 2;
+			} else {
+				const bool wide = p + 8 <= L;  // then max_len >= 8 and sp[0..7] is inside the input
+				uint64_t ow = 0;
+				if (wide) __builtin_memcpy(&ow, sp, 8);
+				for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
+					if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
+					const uint32_t q = vals[j];
+					const uint32_t dist = p - q;
+					if (q == 0 || q == nil_q) break;                         // NIL ends the chain
+					if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
+					const uint8_t *mp = in + q;
+					if (best < max_len) {                                    // only a longer match can replace the best
+						int len = 0;
+						if (wide) {  // one 8-byte load decides most candidates (the loads of mp are the uncoalesced ones)
+							if (best < 8 || mp[best] == sp[best]) {
+								uint64_t cw;
+								__builtin_memcpy(&cw, mp, 8);
+								const uint64_t d = cw ^ ow;
+								len = d ? (__ffsll((long long)d) - 1) >> 3 : common_prefix(mp, sp, 8, max_len);
+							}
+						} else if (mp[best] == sp[best]) len = common_prefix(mp, sp, 0, max_len);
+						if (len > best) { best = len; best_q = q; }
+					}
+					count++;
+					if (best >= max_len) break;                              // len >= nice_match
+				}
 			}
-		} else
-		for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
-			if (count == LIGHT_STEPS) { done = false; break; }        // heavy: finish cooperatively
-			const uint32_t q = vals[j];
-			const uint32_t dist = p - q;
-			if (q == 0 || q == nil_q) break;                         // NIL ends the chain
-			if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
-			const uint8_t *mp = in + q;
-			if (best < max_len && mp[best] == sp[best]) {           // only a longer match can replace the best
-				int len = 0;
-				while (len < max_len && mp[len] == sp[len]) len++;
-				if (len > best) { best = len; best_q = q; }
+			MatchRec r;
+			if (kind == 0) {
+				r.len4096 = r.len1024 = (uint16_t)best;
+				r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
+			} else {  // sentinel carrying the sorted index (and, for run positions, the run length)
+				r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
+				r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
 			}
-			count++;
-			if (best >= max_len) break;                              // len >= nice_match
-		}
-		if (done) {
-			MatchRec r;
-			r.len4096 = r.len1024 = (uint16_t)best;
-			r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
 			mr[p] = r;
-		} else {
-			// sentinel carrying the sorted index.  Deep inside a run of one byte deflate_slow almost never
-			// stops (the run is consumed by one match), so those positions are evaluated only if the parse
-			// really reaches them (dfl_parse_kernel); everything else is queued for the parallel heavy pass.
-			MatchRec r;
-			r.len4096 = 0xFFFF; r.len1024 = 0;
-			r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
-			mr[p] = r;
-			heavy[atomicAdd(&a.heavy_count[s], 1u)] = i;
 		}
+		// wave-aggregated appends: one atomic per wave and list
+		const uint64_t bh = __ballot(kind == 1), br = __ballot(kind == 2);
+		uint32_t base_h = 0, base_r = 0;
+		if (lane == 0) {
+			if (bh) base_h = atomicAdd(&a.heavy_count[s], (uint32_t)__popcll(bh));
+			if (br) base_r = atomicAdd(&a.deep_count[s], (uint32_t)__popcll(br));
+		}
+		base_h = (uint32_t)__shfl((int)base_h, 0, 64); base_r = (uint32_t)__shfl((int)base_r, 0, 64);
+		if (kind == 1) heavy[base_h + (uint32_t)__popcll(bh & lt_mask)] = i;
+		if (kind == 2) *(heavy + a.in_stride - 1 - (base_r + (uint32_t)__popcll(br & lt_mask))) = i;  // grows downwards from the end
 	}
 }
 
@@ -196,9 +298,7 @@ __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint
 		int len = 0;
 		if (lane < nvalid && best < max_len) {
 			const uint8_t *mp = in + q;
-			if (mp[best] == sp[best]) {
-				while (len < max_len && mp[len] == sp[len]) len++;
-			}
+			if (mp[best] == sp[best]) len = common_prefix(mp, sp, 0, max_len);
 		}
 		// longest length in this step, earliest candidate (lowest lane) that reaches it
 		uint64_t cand = __ballot(len > best);
@@ -219,9 +319,10 @@ __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint
 	hi = (best ? p - best_q : 0u) | ((len1024 ? p - q1024 : 0u) << 16);
 }
 
-__global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a)
+__global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int n)
 {
-	const int s = blockIdx.y;
+	int s; uint32_t part, nparts;
+	if (!xcd_slice(n, s, part, nparts)) return;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
@@ -231,7 +332,7 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a)
 	const uint32_t *heavy = a.heavy_list + base;
 	const uint32_t nheavy = a.heavy_count[s];
 	const int lane = threadIdx.x & 63;
-	for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += gridDim.x * (blockDim.x >> 6)) {
+	for (uint32_t e = part * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += nparts * (blockDim.x >> 6)) {
 		const uint32_t i = heavy[e];
 		const uint32_t p = vals[i];
 		uint32_t lo, hi;
@@ -312,9 +413,10 @@ __global__ void __launch_bounds__(256) dfl_run_ends_kernel(DeflateArgs a)
 // So the lane scans run ends backwards, one O(1) step per run.  The limits of deflate.c become position
 // limits: the first K chain entries are the sorted indices i-1 .. i-K (K = 4096, and 1024 for the
 // good_match variant); distance < MAX_DIST; position 0 is NIL.
-__global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a)
+__global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n)
 {
-	const int s = blockIdx.y;
+	int s; uint32_t part, nparts;
+	if (!xcd_slice(n, s, part, nparts)) return;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
@@ -326,7 +428,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a)
 	const uint32_t *re = a.run_ends + base;
 	const uint32_t *rl = re + (a.in_stride >> 1);
 	const uint32_t nre = a.run_end_count[s];
-	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ndeep; e += gridDim.x * blockDim.x) {
+	for (uint32_t e = part * blockDim.x + threadIdx.x; e < ndeep; e += nparts * blockDim.x) {
 		const uint32_t i = *(deep - e);
 		const uint32_t p = vals[i];
 		const uint32_t h = keys[i];
@@ -343,7 +445,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a)
 			if (!have_head || hq == 0 || hq == nil_candidate(p, lookahead) || p - hq > (uint32_t)MAX_DIST) scan = false;
 			else if (p - hq == (uint32_t)MAX_DIST) {  // only the head itself may sit at distance MAX_DIST
 				uint32_t len = 0;
-				while (len < max_len && in[hq + len] == in[p + len]) len++;
+				len = (uint32_t)common_prefix(in + hq, in + p, 0, (int)max_len);
 				best4 = best1 = len; q4 = q1 = hq;
 				scan = false;
 			}
@@ -367,7 +469,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a)
 					uint32_t q, len;
 					if (m == r) {
 						q = x - r; len = r;
-						if (ext_ok && in[x] == c) { len = r + 1; while (len < max_len && in[q + len] == in[p + len]) len++; }
+						if (ext_ok && in[x] == c) len = (uint32_t)common_prefix(in + q, in + p, (int)r + 1, (int)max_len);
 					} else { q = x - m; len = m; }
 					if (len > best4) { best4 = len; q4 = q; }
 					// the same run seen through the 1024-entry limit
@@ -536,6 +638,10 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 }
 
 // ------------------------------------------------------------------ 4. Huffman trees per block (trees.c)
+// One WAVE per (slice, block).  trees.c's heap decides ties by heap position, so the heap itself is replayed
+// by lane 0; everything around it (histogram, leaf list, bit-length statistics, code assignment) is done by
+// all 64 lanes, and the tables the serial parts index are staged in LDS (a __constant__ lookup with a
+// per-lane index is a global load: ~10x the latency of an LDS read when nothing hides it).
 struct TreeScratch {  // one block's working set, in LDS
 	uint16_t freq[HEAP_SIZE], dad[HEAP_SIZE], len[HEAP_SIZE], code[HEAP_SIZE];        // literal/length tree
 	uint16_t dfreq[2 * D_CODES + 1], ddad[2 * D_CODES + 1], dlen[2 * D_CODES + 1], dcode[2 * D_CODES + 1];
@@ -544,21 +650,17 @@ struct TreeScratch {  // one block's working set, in LDS
 	// is (e_n >> 10) <= (e_m >> 10) and one 64-bit LDS read fetches both children (freq <= 16384: 15 bits;
 	// depth <= 21 for that total weight: 5 bits; node < 573: 10 bits)
 	alignas(8) uint32_t heap[HEAP_SIZE + 1];
-	uint8_t depth[HEAP_SIZE];
-	uint16_t bl_count[MAX_BITS + 1];
+	uint32_t bl_count[MAX_BITS + 1];
 	uint16_t next_code[MAX_BITS + 1];
-	int heap_len, heap_max;
+	int heap_len, heap_max, max_code, overflow;
 	uint32_t opt_len, static_len;
 	uint32_t hdr_bits[160];  // dynamic-block header: 14 + 3*19 + up to 316 * 14 bits
 	uint32_t hdr_nbits;
+	// staged tables
+	uint8_t extra_l[29], extra_d[30], extra_bl[19], bl_order[19], static_llen[L_CODES + 2], length_code[256], dist_code[512];
 };
 
 struct TreeView { uint16_t *freq, *dad, *len, *code; };
-
-__device__ __forceinline__ uint32_t heap_entry(const TreeView &t, const uint8_t *depth, int n)
-{
-	return ((uint32_t)t.freq[n] << 15) | ((uint32_t)depth[n] << 10) | (uint32_t)n;
-}
 
 __device__ __forceinline__ void pqdownheap(TreeScratch &S, int k)
 {
@@ -577,90 +679,137 @@ __device__ __forceinline__ void pqdownheap(TreeScratch &S, int k)
 	S.heap[k] = v;
 }
 
-// build_tree + gen_bitlen + gen_codes (trees.c:486-700).  kind: 0 literal/length, 1 distance, 2 bit-length
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+	return v;
+}
+
+// build_tree + gen_bitlen + gen_codes (trees.c:486-700), called by the whole wave.
+// kind: 0 literal/length, 1 distance, 2 bit-length
 __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 {
+	const int lane = threadIdx.x;
 	const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
 	const int max_length = kind == 2 ? MAX_BL_BITS : MAX_BITS;
 	const int base = kind == 0 ? 257 : 0;
-	int n, m, max_code = -1, node;
-	S.heap_len = 0; S.heap_max = HEAP_SIZE;
-	for (n = 0; n < elems; n++) {
-		if (t.freq[n] != 0) { S.depth[n] = 0; S.heap[++S.heap_len] = heap_entry(t, S.depth, max_code = n); }
-		else t.len[n] = 0;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+	// leaves with a non-zero frequency, in symbol order (the initial heap array)
+	int max_code = -1;
+	uint32_t nleaf = 0;
+	for (int n0 = 0; n0 < elems; n0 += 64) {
+		const int n = n0 + lane;
+		const uint32_t f = n < elems ? t.freq[n] : 0u;
+		const uint64_t bal = __ballot(f != 0);
+		if (f != 0) S.heap[1 + nleaf + (uint32_t)__popcll(bal & lt_mask)] = (f << 15) | (uint32_t)n;  // depth 0
+		else if (n < elems) t.len[n] = 0;
+		if (bal) max_code = n0 + 63 - __clzll((long long)bal);
+		nleaf += (uint32_t)__popcll(bal);
 	}
-	while (S.heap_len < 2) {
-		node = max_code < 2 ? ++max_code : 0;
-		t.freq[node] = 1; S.depth[node] = 0; S.opt_len--;
-		S.heap[++S.heap_len] = heap_entry(t, S.depth, node);
-		if (kind == 0) S.static_len -= c_static_llen[node];
-		else if (kind == 1) S.static_len -= 5;
-	}
-	for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, n);
-	node = elems;
-	do {
-		const uint32_t en = S.heap[1];
-		S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, 1);
-		const uint32_t em = S.heap[1];
-		n = (int)(en & 1023u); m = (int)(em & 1023u);
-		S.heap[--S.heap_max] = en; S.heap[--S.heap_max] = em;
-		const uint32_t f = (en >> 15) + (em >> 15);
-		const uint32_t dn = (en >> 10) & 31u, dm = (em >> 10) & 31u;
-		const uint32_t d = (dn >= dm ? dn : dm) + 1;
-		t.freq[node] = (uint16_t)f;
-		S.depth[node] = (uint8_t)d;
-		t.dad[n] = t.dad[m] = (uint16_t)node;
-		S.heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
-		node++;
-		pqdownheap(S, 1);
-	} while (S.heap_len >= 2);
-	S.heap[--S.heap_max] = S.heap[1];
-	// gen_bitlen
-	int h, bits, overflow = 0;
-	for (bits = 0; bits <= MAX_BITS; bits++) S.bl_count[bits] = 0;
-	t.len[S.heap[S.heap_max] & 1023u] = 0;
-	for (h = S.heap_max + 1; h < HEAP_SIZE; h++) {
-		n = (int)(S.heap[h] & 1023u);
-		bits = t.len[t.dad[n]] + 1;
-		if (bits > max_length) { bits = max_length; overflow++; }
-		t.len[n] = (uint16_t)bits;
-		if (n > max_code) continue;
-		S.bl_count[bits]++;
-		int xbits = 0;
-		if (n >= base) xbits = kind == 0 ? c_extra_lbits[n - base] : kind == 1 ? c_extra_dbits[n] : c_extra_blbits[n];
-		const uint32_t f = t.freq[n];
-		S.opt_len += f * (uint32_t)(bits + xbits);
-		if (kind == 0) S.static_len += f * (uint32_t)(c_static_llen[n] + xbits);
-		else if (kind == 1) S.static_len += f * (uint32_t)(5 + xbits);
-	}
-	if (overflow > 0) {
+	__syncthreads();
+	if (lane == 0) {
+		int n, m, node;
+		S.heap_len = (int)nleaf; S.heap_max = HEAP_SIZE;
+		while (S.heap_len < 2) {
+			node = max_code < 2 ? ++max_code : 0;
+			t.freq[node] = 1; S.opt_len--;
+			S.heap[++S.heap_len] = (1u << 15) | (uint32_t)node;
+			if (kind == 0) S.static_len -= S.static_llen[node];
+			else if (kind == 1) S.static_len -= 5;
+		}
+		for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, n);
+		node = elems;
 		do {
-			bits = max_length - 1;
-			while (S.bl_count[bits] == 0) bits--;
-			S.bl_count[bits]--; S.bl_count[bits + 1] += 2; S.bl_count[max_length]--;
-			overflow -= 2;
-		} while (overflow > 0);
-		for (bits = max_length; bits != 0; bits--) {
-			n = S.bl_count[bits];
-			while (n != 0) {
-				m = (int)(S.heap[--h] & 1023u);
-				if (m > max_code) continue;
-				if ((uint32_t)t.len[m] != (uint32_t)bits) {
-					S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
-					t.len[m] = (uint16_t)bits;
+			const uint32_t en = S.heap[1];
+			S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, 1);
+			const uint32_t em = S.heap[1];
+			n = (int)(en & 1023u); m = (int)(em & 1023u);
+			S.heap[--S.heap_max] = en; S.heap[--S.heap_max] = em;
+			const uint32_t f = (en >> 15) + (em >> 15);
+			const uint32_t dn = (en >> 10) & 31u, dm = (em >> 10) & 31u;
+			const uint32_t d = (dn >= dm ? dn : dm) + 1;
+			t.freq[node] = (uint16_t)f;
+			t.dad[n] = t.dad[m] = (uint16_t)node;
+			S.heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
+			node++;
+			pqdownheap(S, 1);
+		} while (S.heap_len >= 2);
+		S.heap[--S.heap_max] = S.heap[1];
+		// gen_bitlen, first loop: depth of every node, clamped (parents precede children in the sorted heap)
+		int h, bits, overflow = 0;
+		t.len[S.heap[S.heap_max] & 1023u] = 0;
+		for (h = S.heap_max + 1; h < HEAP_SIZE; h++) {
+			n = (int)(S.heap[h] & 1023u);
+			bits = t.len[t.dad[n]] + 1;
+			if (bits > max_length) { bits = max_length; overflow++; }
+			t.len[n] = (uint16_t)bits;
+		}
+		S.max_code = max_code; S.overflow = overflow;
+	}
+	if (lane <= MAX_BITS) S.bl_count[lane] = 0;
+	__syncthreads();
+	max_code = S.max_code;
+	// bl_count / opt_len / static_len over the leaves (every leaf of the tree has freq != 0)
+	uint32_t o = 0, st = 0;
+	for (int n = lane; n <= max_code; n += 64) {
+		const uint32_t f = t.freq[n];
+		if (f == 0) continue;
+		const uint32_t bits = t.len[n];
+		atomicAdd(&S.bl_count[bits], 1u);
+		uint32_t xbits = 0;
+		if (n >= base) xbits = kind == 0 ? S.extra_l[n - base] : kind == 1 ? S.extra_d[n] : S.extra_bl[n];
+		o += f * (bits + xbits);
+		if (kind == 0) st += f * ((uint32_t)S.static_llen[n] + xbits);
+		else if (kind == 1) st += f * (5u + xbits);
+	}
+	o = wave_sum(o); st = wave_sum(st);
+	__syncthreads();
+	if (lane == 0) {
+		S.opt_len += o; S.static_len += st;
+		int overflow = S.overflow;
+		if (overflow > 0) {  // rare: move leaves down until the Kraft sum fits (trees.c:540-571)
+			int bits, n, m, h = HEAP_SIZE;
+			do {
+				bits = max_length - 1;
+				while (S.bl_count[bits] == 0) bits--;
+				S.bl_count[bits]--; S.bl_count[bits + 1] += 2; S.bl_count[max_length]--;
+				overflow -= 2;
+			} while (overflow > 0);
+			for (bits = max_length; bits != 0; bits--) {
+				n = (int)S.bl_count[bits];
+				while (n != 0) {
+					m = (int)(S.heap[--h] & 1023u);
+					if (m > max_code) continue;
+					if ((uint32_t)t.len[m] != (uint32_t)bits) {
+						S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
+						t.len[m] = (uint16_t)bits;
+					}
+					n--;
 				}
-				n--;
 			}
 		}
+		uint32_t code = 0;
+		for (int bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; S.next_code[bits] = (uint16_t)code; }
 	}
-	// gen_codes
-	uint32_t code = 0;
-	for (bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; S.next_code[bits] = (uint16_t)code; }
-	for (n = 0; n <= max_code; n++) {
-		const int len = t.len[n];
-		if (len == 0) continue;
-		t.code[n] = (uint16_t)(__brev((uint32_t)S.next_code[len]++) >> (32 - len));
+	__syncthreads();
+	// gen_codes: symbol n gets next_code[len] + (number of lower symbols with the same length), bit-reversed
+	uint32_t seen[MAX_BITS + 1];
+#pragma unroll
+	for (int b = 1; b <= MAX_BITS; b++) seen[b] = S.next_code[b];
+	for (int n0 = 0; n0 <= max_code; n0 += 64) {
+		const int n = n0 + lane;
+		const int len = n <= max_code ? (int)t.len[n] : 0;
+		uint32_t mine = 0;
+#pragma unroll
+		for (int b = 1; b <= MAX_BITS; b++) {
+			const uint64_t bal = __ballot(len == b);
+			if (len == b) mine = seen[b] + (uint32_t)__popcll(bal & lt_mask);
+			seen[b] += (uint32_t)__popcll(bal);
+		}
+		if (len != 0) t.code[n] = (uint16_t)(__brev(mine) >> (32 - len));
 	}
+	__syncthreads();
 	return max_code;
 }
 
@@ -712,8 +861,8 @@ __device__ void send_tree(TreeScratch &S, const TreeView &t, int max_code)
 	}
 }
 
-// one workgroup per (slice, block): histogram by all lanes, trees by lane 0 (trees.c _tr_flush_block)
-__global__ void __launch_bounds__(256) dfl_tree_kernel(DeflateArgs a)
+// one wave per (slice, block): histogram + trees (trees.c _tr_flush_block)
+__global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 {
 	__shared__ TreeScratch S;
 	const int s = blockIdx.y, m = blockIdx.x;
@@ -737,6 +886,12 @@ __global__ void __launch_bounds__(256) dfl_tree_kernel(DeflateArgs a)
 	for (int i = threadIdx.x; i < 2 * D_CODES + 1; i += blockDim.x) { S.dfreq[i] = 0; S.dlen[i] = 0; S.ddad[i] = 0; S.dcode[i] = 0; }
 	for (int i = threadIdx.x; i < 2 * BL_CODES + 1; i += blockDim.x) { S.bfreq[i] = 0; S.blen[i] = 0; S.bdad[i] = 0; S.bcode[i] = 0; }
 	for (int i = threadIdx.x; i < 160; i += blockDim.x) S.hdr_bits[i] = 0;
+	for (int i = threadIdx.x; i < 512; i += blockDim.x) S.dist_code[i] = c_dist_code[i];
+	for (int i = threadIdx.x; i < 256; i += blockDim.x) S.length_code[i] = c_length_code[i];
+	for (int i = threadIdx.x; i < L_CODES + 2; i += blockDim.x) S.static_llen[i] = c_static_llen[i];
+	if (threadIdx.x < 29) S.extra_l[threadIdx.x] = c_extra_lbits[threadIdx.x];
+	if (threadIdx.x < 30) S.extra_d[threadIdx.x] = c_extra_dbits[threadIdx.x];
+	if (threadIdx.x < 19) { S.extra_bl[threadIdx.x] = c_extra_blbits[threadIdx.x]; S.bl_order[threadIdx.x] = c_bl_order[threadIdx.x]; }
 	__shared__ uint32_t hl[L_CODES], hd[D_CODES];
 	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) hl[i] = 0;
 	if (threadIdx.x < D_CODES) hd[threadIdx.x] = 0;
@@ -745,25 +900,31 @@ __global__ void __launch_bounds__(256) dfl_tree_kernel(DeflateArgs a)
 		const uint32_t v = sym[i];
 		const uint32_t dist = v >> 16, lc = v & 0xFFu;
 		if (dist == 0) atomicAdd(&hl[lc], 1u);
-		else { atomicAdd(&hl[c_length_code[lc] + 256 + 1], 1u); atomicAdd(&hd[d_code(dist - 1)], 1u); }
+		else {
+			const uint32_t d1 = dist - 1;
+			atomicAdd(&hl[S.length_code[lc] + 256 + 1], 1u);
+			atomicAdd(&hd[d1 < 256 ? S.dist_code[d1] : S.dist_code[256 + (d1 >> 7)]], 1u);
+		}
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) S.freq[i] = (uint16_t)hl[i];
 	if (threadIdx.x < D_CODES) S.dfreq[threadIdx.x] = (uint16_t)hd[threadIdx.x];
+	if (threadIdx.x == 0) { S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0; }
 	__syncthreads();
+	if (threadIdx.x == 0) S.freq[END_BLOCK] = 1;
+	__syncthreads();
+	const TreeView lt{S.freq, S.dad, S.len, S.code}, dt{S.dfreq, S.ddad, S.dlen, S.dcode}, btv{S.bfreq, S.bdad, S.blen, S.bcode};
+	const int lmax = build_tree(S, lt, 0);
+	const int dmax = build_tree(S, dt, 1);
+	const uint32_t dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
+	__syncthreads();
+	if (threadIdx.x == 0) { scan_tree(S, lt, lmax); scan_tree(S, dt, dmax); }
+	__syncthreads();
+	build_tree(S, btv, 2);
 	if (threadIdx.x == 0) {
-		S.freq[END_BLOCK] = 1;
-		S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0;
-		const TreeView lt{S.freq, S.dad, S.len, S.code}, dt{S.dfreq, S.ddad, S.dlen, S.dcode}, bt{S.bfreq, S.bdad, S.blen, S.bcode};
-		const int lmax = build_tree(S, lt, 0);
-		const int dmax = build_tree(S, dt, 1);
-		const uint32_t dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
-		scan_tree(S, lt, lmax);
-		scan_tree(S, dt, dmax);
-		build_tree(S, bt, 2);
 		int max_blindex;
 		for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
-			if (S.blen[c_bl_order[max_blindex]] != 0) break;
+			if (S.blen[S.bl_order[max_blindex]] != 0) break;
 		S.opt_len += 3 * ((uint32_t)max_blindex + 1) + 5 + 5 + 4;
 		uint32_t opt_lenb = (S.opt_len + 3 + 7) >> 3;
 		const uint32_t static_lenb = (S.static_len + 3 + 7) >> 3;
@@ -782,7 +943,7 @@ __global__ void __launch_bounds__(256) dfl_tree_kernel(DeflateArgs a)
 			hdr_put(S, (uint32_t)(lmax + 1 - 257), 5);
 			hdr_put(S, (uint32_t)(dmax + 1 - 1), 5);
 			hdr_put(S, (uint32_t)(max_blindex + 1 - 4), 4);
-			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[c_bl_order[rank]], 3);
+			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[S.bl_order[rank]], 3);
 			send_tree(S, lt, lmax);
 			send_tree(S, dt, dmax);
 			bm.hdr_nbits = S.hdr_nbits;
@@ -807,10 +968,18 @@ __global__ void __launch_bounds__(256) dfl_adler_kernel(DeflateArgs a)
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	unsigned long long A = 0, B = 0;
-	for (uint32_t i = threadIdx.x; i < L; i += blockDim.x) {
-		const unsigned long long d = in[i];
-		A += d;
-		B += (unsigned long long)(L - i) * d;
+	for (uint32_t i0 = threadIdx.x * 16; i0 < L; i0 += blockDim.x * 16) {
+		if (i0 + 16 <= L) {  // 16 bytes per step: A += sum d, B += (L - i0) * sum d - sum k * d_k
+			uint64_t w[2];
+			__builtin_memcpy(w, in + i0, 16);
+			uint32_t sd = 0, sk = 0;
+#pragma unroll
+			for (int k = 0; k < 16; k++) { const uint32_t d = (uint32_t)(w[k >> 3] >> ((k & 7) * 8)) & 0xFFu; sd += d; sk += (uint32_t)k * d; }
+			A += sd;
+			B += (unsigned long long)(L - i0) * sd - sk;
+		} else {
+			for (uint32_t i = i0; i < L; i++) { const unsigned long long d = in[i]; A += d; B += (unsigned long long)(L - i) * d; }
+		}
 	}
 	sa[threadIdx.x] = A; sb[threadIdx.x] = B;
 	__syncthreads();
@@ -1083,9 +1252,11 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	                                             (unsigned int)total, (unsigned int)n, a.seg_begin, a.seg_end, 0, 15, st)) != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_match_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over keys_in, dead after the sort
+	const int gm = (int)std::min<size_t>(256, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
+	hipLaunchKernelGGL(dfl_match_kernel, dim3(gm, n8), dim3(256), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
