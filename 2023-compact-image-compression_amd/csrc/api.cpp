@@ -387,7 +387,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	if ((rc = g_ctx.z_exitc.ensure(E * 4))) return rc;
 	if ((rc = g_ctx.z_bentry.ensure(E / 64 * 4))) return rc;
 	if ((rc = g_ctx.z_bsym.ensure(E / 64 * 4))) return rc;
-	if ((rc = g_ctx.z_small.ensure((size_t)n * 9 * 4))) return rc;
+	if ((rc = g_ctx.z_small.ensure((size_t)n * (9 + 128) * 4))) return rc;
 	if ((rc = g_ctx.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
 	if ((rc = g_ctx.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
 	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
@@ -412,7 +412,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.vals_in = (uint32_t *)g_ctx.z_vals_in.p; a.vals_out = (uint32_t *)g_ctx.z_vals_out.p;
 	uint32_t *small = (uint32_t *)g_ctx.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
-	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n;
+	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
 	a.mr = g_ctx.z_mr.p; a.heavy_list = (uint32_t *)g_ctx.z_rec.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
 	a.run_ends = (uint32_t *)g_ctx.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
 	a.run_len = (uint16_t *)g_ctx.z_keys_in.p;
@@ -432,7 +432,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 		b.in += eo; b.in_sizes += s0;
 		b.keys_in += eo; b.keys_out += eo; b.vals_in += eo; b.vals_out += eo;
 		b.seg_begin += s0; b.seg_end += s0; b.total_syms += s0; b.postloop_lit += s0; b.n_blocks += s0; b.adler += s0;
-		b.heavy_count += s0; b.deep_count += s0; b.run_end_count += s0;
+		b.heavy_count += s0; b.deep_count += s0; b.run_end_count += s0; b.sort_hist += (size_t)s0 * 128;
 		b.mr = (uint8_t *)b.mr + eo * 8; b.heavy_list += eo; b.sym += eo; b.run_ends += eo; b.run_len += eo;
 		b.rec32 += eo; b.exit_pos += eo; b.exit_cnt += eo;
 		b.blk_entry += bo; b.blk_symbase += bo;

@@ -87,6 +87,7 @@ struct DeflateArgs {
 	uint32_t *seg_begin, *seg_end;                                   // n
 	void *mr;                                                        // n * in_stride * 8 bytes
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each
+	uint32_t *sort_hist;                                             // n * 128: histogram of hash >> 8 per slice (pass A -> pass B)
 	uint16_t *run_len;                                               // n * in_stride: equal bytes ahead (<= 258) | has_prev << 15
 	uint32_t *rec32, *exit_pos, *exit_cnt;                           // n * in_stride each
 	uint32_t *blk_entry, *blk_symbase;                               // n * in_stride / 64

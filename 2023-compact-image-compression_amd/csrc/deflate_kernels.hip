@@ -20,7 +20,6 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "cct_internal.h"
 #include "../../include/compact_hip.h"
@@ -53,22 +52,94 @@ __device__ __forceinline__ int d_code(uint32_t dist) { return dist < 256 ? c_dis
 
 struct MatchRec { uint16_t len4096, len1024, dist4096, dist1024; };
 
-// ------------------------------------------------------------------ 1. hash + segment bounds
-__global__ void dfl_hash_kernel(DeflateArgs a)
+// ------------------------------------------------------------------ 1. hash + sort by (hash, position)
+// The chain of a string = the earlier strings with the same 15-bit hash, most recent first (deflate.c
+// INSERT_STRING / prev[]).  Sorting the positions of a slice by (hash, position) lays every chain out as a
+// contiguous run.  Stable LSD radix sort in two passes (hash & 255, then hash >> 8); ONE workgroup of 1024 lanes
+// per slice walks its slice tile by tile with running digit offsets in LDS, so there is no cross-workgroup
+// scan: pass A hashes the input on the fly (value = position = index) and also counts pass B's digits.
+// Per tile: wave-level match-any gives each lane its rank among the equal digits of its wave, the 16 per-wave
+// counts are prefix-summed per digit, and lanes scatter to offset[digit] + wave prefix + rank.
+template <bool FIRST>
+__global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 {
-	const int s = blockIdx.y;
+	constexpr int BITS = FIRST ? 8 : 7, NB = 1 << BITS;
+	__shared__ uint32_t offs[256];
+	__shared__ uint32_t wcnt[16][NB];
+	__shared__ uint32_t next_hist[128];
+	const int s = blockIdx.x;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
 	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		a.seg_begin[s] = (uint32_t)base;
-		a.seg_end[s] = (uint32_t)(base + npos);
+	const uint16_t *keys_src = a.keys_in + base;
+	const uint32_t *vals_src = a.vals_in + base;
+	uint16_t *keys_dst = (FIRST ? a.keys_in : a.keys_out) + base;
+	uint32_t *vals_dst = (FIRST ? a.vals_in : a.vals_out) + base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+	if (tid < 256) offs[tid] = 0;
+	if (tid < 128) next_hist[tid] = 0;
+	__syncthreads();
+	// digit histogram of this pass
+	if (FIRST) {
+		for (uint32_t p = tid; p < npos; p += 1024) {
+			const uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFFu;
+			atomicAdd(&offs[h & 255u], 1u);
+		}
+	} else if (tid < NB) offs[tid] = a.sort_hist[(size_t)s * 128 + tid];
+	__syncthreads();
+	if (wave == 0) {  // exclusive scan of up to 256 bins: 4 per lane
+		uint32_t v[4], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { v[k] = offs[lane * 4 + k]; sum += v[k]; }
+		uint32_t inc = sum;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+		uint32_t run = inc - sum;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { offs[lane * 4 + k] = run; run += v[k]; }
 	}
-	for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npos; p += gridDim.x * blockDim.x) {
-		const uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFFu;
-		a.keys_in[base + p] = (uint16_t)h;
-		a.vals_in[base + p] = p;
+	__syncthreads();
+	for (uint32_t t0 = 0; t0 < npos; t0 += 1024) {
+		const uint32_t idx = t0 + tid;
+		const bool valid = idx < npos;
+		uint32_t h = 0, p = idx;
+		if (valid) {
+			if (FIRST) h = (((uint32_t)in[idx] << 10) ^ ((uint32_t)in[idx + 1] << 5) ^ in[idx + 2]) & 0x7FFFu;
+			else { h = keys_src[idx]; p = vals_src[idx]; }
+		}
+		const uint32_t d = FIRST ? (h & 255u) : (h >> 8);
+		for (int k = lane; k < NB; k += 64) wcnt[wave][k] = 0;
+		uint64_t same = __ballot(valid);  // lanes of this wave with the same digit
+#pragma unroll
+		for (int b = 0; b < BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t bal = __ballot(bit);
+			same &= bit ? bal : ~bal;
+		}
+		const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
+		if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);
+		if (FIRST && valid) atomicAdd(&next_hist[h >> 8], 1u);
+		__syncthreads();
+		if (tid < NB) {  // running offset of digit tid, handed out wave by wave
+			uint32_t c[16], run = offs[tid];
+#pragma unroll
+			for (int w = 0; w < 16; w++) c[w] = wcnt[w][tid];
+#pragma unroll
+			for (int w = 0; w < 16; w++) { wcnt[w][tid] = run; run += c[w]; }
+			offs[tid] = run;
+		}
+		__syncthreads();
+		if (valid) {
+			const uint32_t dst = wcnt[wave][d] + rank;
+			keys_dst[dst] = (uint16_t)h;
+			vals_dst[dst] = p;
+		}
+	}
+	if (FIRST) {
+		__syncthreads();
+		if (tid < 128) a.sort_hist[(size_t)s * 128 + tid] = next_hist[tid];
 	}
 }
 
@@ -1232,25 +1303,19 @@ hipError_t deflate_init_tables()
 
 size_t deflate_sort_temp_bytes(size_t total, int n)
 {
-	size_t bytes = 0;
-	(void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (uint16_t *)nullptr, (uint16_t *)nullptr, (uint32_t *)nullptr,
-	                                          (uint32_t *)nullptr, (unsigned int)total, (unsigned int)n, (uint32_t *)nullptr,
-	                                          (uint32_t *)nullptr, 0, 15, (hipStream_t)0);
-	return bytes;
+	(void)total; (void)n;
+	return 0;  // the sort keeps its state in LDS (dfl_sort_pass_kernel)
 }
 
 hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st)
 {
-	const size_t total = (size_t)n * a.in_stride;
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
-	hipLaunchKernelGGL(dfl_hash_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	size_t tb = sort_temp_bytes;
-	if ((e = rocprim::segmented_radix_sort_pairs(sort_temp, tb, a.keys_in, a.keys_out, a.vals_in, a.vals_out,
-	                                             (unsigned int)total, (unsigned int)n, a.seg_begin, a.seg_end, 0, 15, st)) != hipSuccess)
-		return e;
+	(void)sort_temp; (void)sort_temp_bytes;
+	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> (keys_in, vals_in) by hash & 255
+	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> (keys_out, vals_out) by hash >> 8
 	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over keys_in, dead after the sort
 	const int gm = (int)std::min<size_t>(256, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
