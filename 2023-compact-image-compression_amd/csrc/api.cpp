@@ -736,6 +736,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 1, g_ctx.stream));
 				HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
 				HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+				const double t_c1 = now_ms();
 				const int nt = std::min(g_ctx.zlib_threads, 16);
 				const size_t per = (exact + nt - 1) / nt;
 				const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
@@ -745,6 +746,9 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				});
 				for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
 				g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
+				if (getenv("CCT_TRACE"))
+					fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
+					        g_ctx.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, exact);
 				continue;
 			}
 			HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
@@ -975,9 +979,13 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	{  // device phase on the decode stream (no device lock: the HIP runtime is thread-safe)
 		hipStream_t st = g_ctx.stream_dec;
 		g_ctx.t_inflate_ms = t_inflate;
-		for (int i = 0; i < n; i++)
-			HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.d_payload.p + (size_t)i * stride, stage + (size_t)i * stride,
-			                       (psz[i] + 15u) & ~15u, hipMemcpyHostToDevice, st));
+		// one strided copy of the used part of every staged payload (a copy per slice costs more in launches
+		// than in bytes)
+		size_t used = 16;
+		for (int i = 0; i < n; i++) used = std::max(used, (size_t)((psz[i] + 15u) & ~15u));
+		used = std::min(used, stride);
+		const double t_h0 = now_ms();
+		HIP_TRY(hipMemcpy2DAsync(g_ctx.d_payload.p, stride, stage, stride, used, (size_t)n, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(g_ctx.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 		uint16_t *d_img = images_on_device ? images : (uint16_t *)g_ctx.d_images.p;
 		HIP_TRY(hipEventRecord(g_ctx.ev_d0, st));
@@ -990,6 +998,9 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		if (getenv("CCT_TRACE"))
+			fprintf(stderr, "[cct] decode n=%d: inflate %.2f ms, h2d+kernel+sync %.2f ms (kernel %.2f), used %zu of stride %zu\n", n,
+			        t_inflate, now_ms() - t_h0, g_ctx.t_dec_kernel_ms, used, stride);
 	}
 	}
 	int first = CCT_OK;

@@ -60,6 +60,13 @@ struct MatchRec { uint16_t len4096, len1024, dist4096, dist1024; };
 // scan: pass A hashes the input on the fly (value = position = index) and also counts pass B's digits.
 // Per tile: wave-level match-any gives each lane its rank among the equal digits of its wave, the 16 per-wave
 // counts are prefix-summed per digit, and lanes scatter to offset[digit] + wave prefix + rank.
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would serialise the
+// scattered stores of a tile with its barriers
+__device__ __forceinline__ void lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <bool FIRST>
 __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 {
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
 		if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);
 		if (FIRST && valid) atomicAdd(&next_hist[h >> 8], 1u);
-		__syncthreads();
+		lds_barrier();
 		if (tid < NB) {  // running offset of digit tid, handed out wave by wave
 			uint32_t c[16], run = offs[tid];
 #pragma unroll
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			for (int w = 0; w < 16; w++) { wcnt[w][tid] = run; run += c[w]; }
 			offs[tid] = run;
 		}
-		__syncthreads();
+		lds_barrier();
 		if (valid) {
 			const uint32_t dst = wcnt[wave][d] + rank;
 			keys_dst[dst] = (uint16_t)h;
