@@ -165,8 +165,17 @@ int ensure_ctx(int device = -1)
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
 	if (g_ctx.zlib_threads <= 0) {
+		// host team size: the CPUs this process may actually use.  Under a cgroup CPU quota (cpu.max) more
+		// runnable threads than about twice the quota only get the whole process throttled.
 		unsigned hc = std::thread::hardware_concurrency();
-		g_ctx.zlib_threads = hc ? (int)hc : 1;
+		int nt = hc ? (int)hc : 1;
+		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+			long long quota = 0, period = 0;
+			if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+				nt = std::min(nt, (int)std::max<long long>(1, 2 * ((quota + period - 1) / period)));
+			fclose(f);
+		}
+		g_ctx.zlib_threads = nt;
 	}
 	g_ctx.ready = true;
 	return CCT_OK;

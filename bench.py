@@ -76,8 +76,8 @@ def cpu_baseline(batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slices", type=int, default=SLICES_PER_GPU, help="slices per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
@@ -101,7 +101,11 @@ def main():
     _ffi.check(L.cct_init(local_rank))
     info = cct_hip.device_info()
     ncpu = os.cpu_count() or 1
-    zthreads = max(1, ncpu // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    # host team: the library sizes it from the CPUs this process may use (cgroup quota aware); ranks of one node
+    # share them
+    zt = C.c_int(0)
+    _ffi.check(L.cct_get_option(b"zlib_threads", C.byref(zt)))
+    zthreads = max(1, zt.value // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     if os.environ.get("CCT_HOST_THREADS"):
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
