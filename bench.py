@@ -112,8 +112,11 @@ def main():
 
     if os.environ.get("CCT_DEFLATE_WAYS"):
         _ffi.check(L.cct_set_option(b"deflate_ways", int(os.environ["CCT_DEFLATE_WAYS"])))
-    dev_deflate = C.c_int(0)
+    if os.environ.get("CCT_DEVICE_INFLATE"):
+        _ffi.check(L.cct_set_option(b"device_inflate", int(os.environ["CCT_DEVICE_INFLATE"])))
+    dev_deflate, dev_inflate = C.c_int(0), C.c_int(0)
     _ffi.check(L.cct_get_option(b"device_deflate", C.byref(dev_deflate)))
+    _ffi.check(L.cct_get_option(b"device_inflate", C.byref(dev_inflate)))
     cfg = cct_hip.default_config()
     cfg["verbose"] = False
     flags, bs, eof, magic, ch, bpc = cct_hip.codec_params(cfg, np.uint16)
@@ -248,7 +251,8 @@ def main():
                 "ms": {k: round(acc[k] / K, 3) for k in ("enc_kernel", "d2h", "deflate", "inflate", "dec_kernel", "enc",
                                                          "dec", "gather")},
                 "deflate": "device (deflate_kernels.hip, byte-identical to zlib 1.2.11 level 9)" if dev_deflate.value
-                else "host libz thread team", "inflate": "host libz thread team",
+                else "host libz thread team", "inflate": "device (inflate_kernels.hip, speculative lane-parallel decode)" if dev_inflate.value
+                else "host libz thread team",
                 "host_threads": zthreads, "host_cpus": ncpu,
                 "compression_ratio": round(2.0 * npx * K / max(1, acc["file_bytes"]), 4)},
             "device": info["name"], "verified": verified,
