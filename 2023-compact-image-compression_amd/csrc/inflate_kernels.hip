@@ -45,10 +45,7 @@ __constant__ uint16_t c_dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,
 __constant__ uint8_t c_dext[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
 __constant__ uint8_t c_clorder[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
 
-struct Huff {          // canonical code of the code-length alphabet (puff.c style), in LDS
-	uint16_t count[16];  // number of codes of each length
-	uint16_t symbol[32]; // symbols ordered by (length, symbol)
-};
+constexpr int CL_BITS = 7;  // code-length codes are at most 7 bits long: one flat table
 
 struct InfShared {
 	uint8_t ring[INF_RING];
@@ -59,7 +56,7 @@ struct InfShared {
 	uint32_t ll_tab[1 << LL_BITS], d_tab[1 << D_BITS];
 	uint32_t ll_sub[LL_SUB], d_sub[D_SUB];
 	uint32_t cnt[16];
-	Huff cl;
+	uint8_t cl_tab[1 << CL_BITS];               // symbol << 3 | code length, 0 = no such code
 	uint8_t lens[320];
 	uint2 mlist[MLIST_CAP];                     // x = destination, y = length | (distance - 1) << 9
 	uint16_t lbase[29], dbase[30];
@@ -115,39 +112,28 @@ __device__ __forceinline__ uint32_t getbits(BitReader &br, int n)
 	return v;
 }
 
-// canonical decode, one bit at a time (puff.c decode()); returns -1 on an invalid code
-__device__ int slow_decode(BitReader &br, const Huff &h)
-{
-	int code = 0, first = 0, index = 0;
-	for (int len = 1; len <= 7; len++) {
-		code |= (int)getbits(br, 1);
-		const int count = h.count[len];
-		if (code - count < first) return h.symbol[index + (code - first)];
-		index += count;
-		first += count;
-		first <<= 1;
-		code <<= 1;
-	}
-	return -1;
-}
-
 // code-length alphabet (19 symbols, <= 7 bits) from S.lens[0..19), by thread 0; S.ok = 0 if over-subscribed
 __device__ void build_cl(InfShared &S)
 {
+	for (int i = threadIdx.x; i < (1 << CL_BITS); i += NT) S.cl_tab[i] = 0;
+	__syncthreads();
 	if (threadIdx.x == 0) {
-		Huff &h = S.cl;
-		for (int i = 0; i < 16; i++) h.count[i] = 0;
-		for (int s = 0; s < 19; s++) h.count[S.lens[s]]++;
-		int left = 1, ok = 1;
-		uint16_t offs[16];
-		offs[1] = 0;
-		for (int len = 1; len <= 15; len++) {
-			left <<= 1;
-			left -= h.count[len];
+		int count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ok = 1, left = 1;
+		for (int s = 0; s < 19; s++) count[S.lens[s] & 7]++;  // 3-bit fields: lengths are 0..7
+		uint32_t next[8], c = 0;
+		next[0] = 0;
+		for (int len = 1; len <= 7; len++) {
+			left = (left << 1) - count[len];
 			if (left < 0) ok = 0;
-			if (len < 15) offs[len + 1] = (uint16_t)(offs[len] + h.count[len]);
+			c = (c + (len > 1 ? (uint32_t)count[len - 1] : 0u)) << 1;
+			next[len] = c;
 		}
-		for (int s = 0; s < 19; s++) if (S.lens[s]) h.symbol[offs[S.lens[s]]++] = (uint16_t)s;
+		for (int s = 0; ok && s < 19; s++) {
+			const int l = S.lens[s];
+			if (!l) continue;
+			const uint32_t r = __brev(next[l]++) >> (32 - l);
+			for (uint32_t k = r; k < (1u << CL_BITS); k += (1u << l)) S.cl_tab[k] = (uint8_t)((s << 3) | l);
+		}
 		S.ok = ok;
 	}
 	__syncthreads();
@@ -441,8 +427,10 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			uint8_t prev_len = 0;
 			while (idx < nlen + ndist) {
 				refill(S, br);
-				const int sym = slow_decode(br, S.cl);
-				if (sym < 0) { err = CCT_ST_ZLIB; break; }
+				const uint32_t ce = S.cl_tab[br.buf & ((1u << CL_BITS) - 1u)];
+				if (ce == 0) { err = CCT_ST_ZLIB; break; }
+				getbits(br, (int)(ce & 7u));
+				const int sym = (int)(ce >> 3);
 				if (sym < 16) { if (tid == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
 				else {
 					int rep; uint8_t v = 0;
@@ -523,7 +511,7 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 				if (k < nmatch_round) m = S.mlist[k];
 				const uint32_t len = m.y & 511u, dist = (m.y >> 9) + 1u;
 				const uint32_t first_dst = S.mlist[k0].x;
-				const bool indep = k < nmatch_round && m.x - dist + len <= first_dst;
+				const bool indep = k < nmatch_round && len <= 16u && m.x - dist + len <= first_dst;  // long copies: everybody
 				const int nind = first_lane_with(S, !indep, 1);  // leading independent copies
 				if (tid < nind) {
 					for (uint32_t i = 0; i < len; i++) S.ring[(m.x + i) & INF_RMASK] = S.ring[(m.x - dist + i) & INF_RMASK];
