@@ -98,8 +98,8 @@ struct Context {
 	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
 	bool z_tables_ready = false;
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
-	int device_inflate = 0;  // option "device_inflate": 1 = INFLATE on the device (one wave per stream; correct but ~15x slower than
-	                         // 256 host threads at 256 streams: the Huffman decode is a serial chain), 0 = libz on the host team
+	int device_inflate = 1;  // option "device_inflate": 1 = INFLATE on the device (inflate_kernels.hip, speculative lane-parallel
+	                         // decode), 0 = libz on the host thread team (same bytes; bounded by the host CPUs the process may use)
 	DevBuf d_arch, d_archoffs, d_zstatus;
 	float t_dev_deflate_ms = 0;
 	int zlib_threads = 0;

@@ -64,6 +64,7 @@ struct InfShared {
 	// round state
 	uint32_t land[NT];                          // landing position of every lane, bits from the round's origin
 	uint32_t wsum_b[4], wsum_m[4], wred[8];
+	uint32_t rres[4];                           // result of the round: bytes, copies, landing position, flags of its last lane
 	int ok;
 };
 
@@ -500,9 +501,9 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 				uint32_t l2, b2, m2;
 				walk_segment<true>(S, org_dword, start, seg_end, l2, b2, m2, efl, o, mi);
 			}
-			if (tid == lastl) { S.wred[4] = cb; S.wred[5] = cm; S.wred[6] = land; S.wred[7] = fl; }
+			if (tid == lastl) { S.rres[0] = cb; S.rres[1] = cm; S.rres[2] = land; S.rres[3] = fl; }
 			if (__syncthreads_or(mine && (efl & SEG_BAD))) { err |= CCT_ST_ZLIB; break; }
-			const uint32_t round_bytes = S.wred[4], nmatch_round = S.wred[5], round_land = S.wred[6], lfl = S.wred[7];
+			const uint32_t round_bytes = S.rres[0], nmatch_round = S.rres[1], round_land = S.rres[2], lfl = S.rres[3];
 			// LZ77 copies in stream order: a copy whose source ends before the first unresolved destination
 			// does not depend on the others of its batch and is done by one lane; a dependent one by everybody
 			for (uint32_t k0 = 0; k0 < nmatch_round;) {

@@ -98,7 +98,7 @@ def _decode_both(hip, files, cfg):
         try:
             outs.append(hip.decode_batch(files, cfg))
         finally:
-            _ffi.check(L.cct_set_option(b"device_inflate", 0))
+            _ffi.check(L.cct_set_option(b"device_inflate", 1))
     assert np.array_equal(outs[0], outs[1])
     return outs[0]
 
@@ -149,4 +149,4 @@ def test_device_inflate_rejects_bad_streams_like_zlib(hip):
                 with pytest.raises(zlib.error):
                     hip.decode_batch([blob], cfg)
             finally:
-                _ffi.check(_ffi.lib().cct_set_option(b"device_inflate", 0))
+                _ffi.check(_ffi.lib().cct_set_option(b"device_inflate", 1))
