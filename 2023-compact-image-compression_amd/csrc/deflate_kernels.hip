@@ -425,61 +425,75 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 // followed by the same byte c = in[p+r], can be longer.  So instead of 4096 chain steps the lane scans
 // the (much shorter) list of run ends backwards.  Chain-length limits translate into position limits
 // through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
-__global__ void __launch_bounds__(256) dfl_run_ends_kernel(DeflateArgs a)
+__global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
 {
-	// one workgroup per slice: ordered compaction of the ends AND starts of runs of >= 3 equal bytes, four
-	// positions per lane.  The k-th start belongs to the k-th end, which gives the run length without scanning.
+	// one workgroup per slice: ordered lists of the ends AND starts of runs of >= 3 equal bytes.  Every lane scans
+	// a contiguous stretch of the slice twice (count, then write at the scanned offsets); a run is reported by the
+	// lane that sees its third byte (start) and the byte after it (end), which keeps both lists in position order.
+	// The k-th start belongs to the k-th end, which gives the run length without scanning.
 	// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
-	__shared__ uint32_t wsum[4];
-	__shared__ uint32_t s_base_e, s_base_s;
+	__shared__ uint32_t wsum_e[16], wsum_s[16];
 	const int s = blockIdx.x;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
 	uint32_t *rs = re + (a.in_stride >> 2);
 	uint32_t *rl = re + (a.in_stride >> 1);
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) { s_base_e = 0; s_base_s = 0; }
-	__syncthreads();
-	for (uint32_t x0 = 0; x0 < L; x0 += blockDim.x * 4) {
-		const uint32_t x = x0 + threadIdx.x * 4;
-		// bytes in[x-3 .. x+5], kept as c[0..8]
-		uint8_t c[9];
-#pragma unroll
-		for (int k = 0; k < 9; k++) { const int64_t y = (int64_t)x - 3 + k; c[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
-		uint32_t me = 0, ms = 0;
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint32_t y = x + k;  // c[k + 3] = in[y]
-			const bool e = y >= 3 && y < L && c[k + 2] == c[k + 1] && c[k + 1] == c[k] && c[k + 3] != c[k + 2];
-			const bool st = y + 2 < L && c[k + 4] == c[k + 3] && c[k + 5] == c[k + 3] && (y == 0 || c[k + 2] != c[k + 3]);
-			me |= (uint32_t)e << k; ms |= (uint32_t)st << k;
-		}
-		const uint32_t cnt = (uint32_t)__popc(me) | ((uint32_t)__popc(ms) << 16);
-		uint32_t inc = cnt;  // inclusive wave scan of both counters at once
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
-		if (lane == 63) wsum[wave] = inc;
-		__syncthreads();
-		uint32_t wb = 0, tot = 0;
-		for (int w = 0; w < 4; w++) { if (w < wave) wb += wsum[w]; tot += wsum[w]; }
-		const uint32_t excl = wb + inc - cnt;
-		uint32_t ie = s_base_e + (excl & 0xFFFFu), is = s_base_s + (excl >> 16);
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			if ((me >> k) & 1u) re[ie++] = x + k;
-			if ((ms >> k) & 1u) rs[is++] = x + k;
-		}
-		__syncthreads();
-		if (threadIdx.x == 0) { s_base_e += tot & 0xFFFFu; s_base_s += tot >> 16; }
-		__syncthreads();
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t per = (((L + 1023) / 1024) + 7) & ~7u;
+	const uint32_t x0 = min(L, (uint32_t)tid * per), x1 = min(L, x0 + per);
+	// equal bytes ending at x0 - 1, capped at 3
+	uint32_t run0 = 0;
+	if (x0 >= 1 && x0 < L) {
+		run0 = 1;
+		if (x0 >= 2 && in[x0 - 2] == in[x0 - 1]) { run0 = 2; if (x0 >= 3 && in[x0 - 3] == in[x0 - 1]) run0 = 3; }
 	}
-	const uint32_t nre = s_base_e;
-	for (uint32_t t = threadIdx.x; t < nre; t += blockDim.x) {
+	uint32_t ie = 0, is = 0, nre = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		uint32_t run = run0, ne = 0, ns = 0;
+		uint8_t prev = x0 >= 1 && x0 < L ? in[x0 - 1] : 0;
+		for (uint32_t xb = x0; xb < x1; xb += 8) {
+			uint64_t w = 0;
+			if (xb + 8 <= L) __builtin_memcpy(&w, in + xb, 8);
+			else for (uint32_t k = 0; xb + k < L; k++) w |= (uint64_t)in[xb + k] << (8 * k);
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const uint32_t x = xb + k;
+				if (x < x1) {
+					const uint8_t c = (uint8_t)(w >> (8 * k));
+					if (x >= 1 && c == prev) {
+						if (run == 2) { if (pass) rs[is + ns] = x - 2; ns++; }
+						if (run < 3) run++;
+					} else {
+						if (run == 3) { if (pass) re[ie + ne] = x; ne++; }
+						run = 1;
+					}
+					prev = c;
+				}
+			}
+		}
+		if (pass == 0) {  // exclusive scans of both counters over the workgroup
+			uint32_t inc_e = ne, inc_s = ns;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t oe = __shfl_up(inc_e, d, 64), os = __shfl_up(inc_s, d, 64);
+				if (lane >= d) { inc_e += oe; inc_s += os; }
+			}
+			if (lane == 63) { wsum_e[wave] = inc_e; wsum_s[wave] = inc_s; }
+			__syncthreads();
+			ie = inc_e - ne; is = inc_s - ns;
+			uint32_t tot = 0;
+			for (int w2 = 0; w2 < 16; w2++) { if (w2 < wave) { ie += wsum_e[w2]; is += wsum_s[w2]; } tot += wsum_e[w2]; }
+			nre = tot;
+		}
+	}
+	if (tid == 0) a.run_end_count[s] = nre;
+	__threadfence();
+	__syncthreads();
+	for (uint32_t t = tid; t < nre; t += 1024) {
 		const uint32_t x = re[t], len = x - rs[t];
 		rl[t] = (len < 511u ? len : 511u) | ((uint32_t)in[x - 1] << 16);
 	}
-	if (threadIdx.x == 0) a.run_end_count[s] = nre;
 }
 
 // Positions p whose string starts with three equal bytes b (r = number of b's from p, capped).
@@ -623,44 +637,58 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 }
 
 // ------------------------------------------------------------------ 3b. block-to-block walk (one workgroup per slice)
-// The hop chain is serial, so its cost is latency: the exit tables are staged through LDS in windows
-// by the whole workgroup and one lane hops inside the window.
-constexpr int WK_WIN = 4096;
+// The parse enters 64-position block b at exit_pos[previous entry]; that hop chain is serial (~4500 hops per
+// slice), but its only state is the position, and chains that start at different positions merge as soon as
+// they share one decision position.  So the slice is cut into 256 segments: every lane hops through its own
+// segment from a speculative start (the segment boundary), then restarts from where its predecessor really
+// landed until no start moves any more (lane k is final after k passes at the latest; typically 2-3 passes
+// of ~18 hops).  A prefix sum over the symbol counts gives every lane its symbol base, and a last pass
+// publishes entry position and symbol base of every block the parse really enters.
 __global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 {
-	__shared__ uint32_t w_pos[WK_WIN], w_cnt[WK_WIN];
-	__shared__ uint32_t s_cur, s_syms;
+	__shared__ uint32_t s_land[256];
+	__shared__ uint32_t s_wsum[4];
 	const int s = blockIdx.x;
 	(void)n;
 	const uint32_t L = a.in_sizes[s];
 	const size_t base = (size_t)s * a.in_stride;
 	const size_t bbase = (size_t)s * (a.in_stride / 64);
-	if (threadIdx.x == 0) { s_cur = 0; s_syms = 0; }
-	__syncthreads();
+	const uint32_t *exit_pos = a.exit_pos + base, *exit_cnt = a.exit_cnt + base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t seg = (((L + 255) / 256) + 63) & ~63u;
+	const uint32_t seg_end = min(L, (uint32_t)(tid + 1) * seg);
+	uint32_t start = min(L, (uint32_t)tid * seg), land = start, cnt = 0;
+	auto hop_through = [&]() {
+		uint32_t cur = start, c = 0;
+		while (cur < seg_end) { c += exit_cnt[cur]; cur = exit_pos[cur]; }
+		land = cur; cnt = c;
+	};
+	hop_through();
 	for (;;) {
-		const uint32_t cur0 = s_cur;
-		if (cur0 >= L) break;
-		const uint32_t w0 = cur0 & ~63u;  // window [w0, w0 + WK_WIN)
-		for (uint32_t t = threadIdx.x; t < (uint32_t)WK_WIN; t += blockDim.x) {
-			const uint32_t x = w0 + t;
-			w_pos[t] = x < a.in_stride ? a.exit_pos[base + x] : 0xFFFFFFFFu;
-			w_cnt[t] = x < a.in_stride ? a.exit_cnt[base + x] : 0u;
-		}
 		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint32_t cur = cur0, syms = s_syms;
-			while (cur < L && cur - w0 < (uint32_t)WK_WIN) {
-				const uint32_t b = cur >> 6;
-				a.blk_entry[bbase + b] = cur;
-				a.blk_symbase[bbase + b] = syms;
-				syms += w_cnt[cur - w0];
-				cur = w_pos[cur - w0];
-			}
-			s_cur = cur; s_syms = syms;
-		}
+		s_land[tid] = land;
 		__syncthreads();
+		const uint32_t pl = tid ? s_land[tid - 1] : 0u;
+		const bool moved = tid > 0 && pl != start;
+		if (!__syncthreads_or(moved)) break;
+		if (moved) { start = pl; hop_through(); }
 	}
-	if (threadIdx.x == 0) a.total_syms[s] = s_syms;
+	// symbols before this lane's segment
+	uint32_t inc = cnt;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+	if (lane == 63) s_wsum[wave] = inc;
+	__syncthreads();
+	uint32_t syms = inc - cnt;
+	for (int w = 0; w < wave; w++) syms += s_wsum[w];
+	if (tid == 255) a.total_syms[s] = syms + cnt;
+	for (uint32_t cur = start; cur < seg_end;) {
+		const uint32_t b = cur >> 6;
+		a.blk_entry[bbase + b] = cur;
+		a.blk_symbase[bbase + b] = syms;
+		syms += exit_cnt[cur];
+		cur = exit_pos[cur];
+	}
 }
 
 // ------------------------------------------------------------------ 3c. symbols in stream order
@@ -1323,7 +1351,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	(void)sort_temp; (void)sort_temp_bytes;
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> (keys_in, vals_in) by hash & 255
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> (keys_out, vals_out) by hash >> 8
-	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over keys_in, dead after the sort
 	const int gm = (int)std::min<size_t>(256, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
 	hipLaunchKernelGGL(dfl_match_kernel, dim3(gm, n8), dim3(256), 0, st, a, n);
