@@ -44,6 +44,8 @@ _SIGS = {
     "cct_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "cct_dev_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "cct_dev_free": (C.c_int, [C.c_void_p]),
+    "cct_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cct_host_free": (C.c_int, [C.c_void_p]),
     "cct_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cct_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cct_dev_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),

@@ -96,6 +96,32 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """Page-locked host bytes (cct_host_alloc) seen as a numpy uint8 array: archives kept here move to and from
+    the device without a staging copy."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p(0)
+        _ffi.check(_ffi.lib().cct_host_alloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            _ffi.check(_ffi.lib().cct_host_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _ffi.lib().cct_host_free(self.ptr)
+                self.ptr = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class Event:
     """HIP event on the library's stream (bench.py times kernels with these)."""
 

@@ -550,6 +550,33 @@ int cct_dev_free(void *d_ptr)
 	HIP_TRY(hipFree(d_ptr));
 	return CCT_OK;
 }
+int cct_host_alloc(void **h_ptr, size_t bytes)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+	return CCT_OK;
+}
+int cct_host_free(void *h_ptr)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	int rc = ensure_ctx();
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipHostFree(h_ptr));
+	return CCT_OK;
+}
+// is [p, p + bytes) page-locked host memory (cct_host_alloc / hipHostMalloc / hipHostRegister)?
+static bool is_pinned_host(const void *p, size_t bytes)
+{
+	hipPointerAttribute_t at{};
+	if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+	if (at.type != hipMemoryTypeHost) return false;
+	hipPointerAttribute_t at2{};
+	if (bytes > 1 && hipPointerGetAttributes(&at2, (const uint8_t *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return bytes <= 1 || at2.type == hipMemoryTypeHost;
+}
 int cct_h2d(void *d_dst, const void *h_src, size_t bytes)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -743,16 +770,23 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				if (at + exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + exact));
 				HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
 				                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 1, g_ctx.stream));
-				HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
-				HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-				const double t_c1 = now_ms();
-				const int nt = std::min(g_ctx.zlib_threads, 16);
-				const size_t per = (exact + nt - 1) / nt;
-				const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
-				parallel_for(nt, nt, [&](int t) {
-					const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
-					if (lo < hi) memcpy(h_out + at + lo, stg + lo, hi - lo);
-				});
+				double t_c1;
+				if (is_pinned_host(h_out + at, exact)) {  // the caller's archive is page-locked: no staging pass
+					HIP_TRY(hipMemcpyAsync(h_out + at, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
+					HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+					t_c1 = now_ms();
+				} else {
+					HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
+					HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+					t_c1 = now_ms();
+					const int nt = std::min(g_ctx.zlib_threads, 16);
+					const size_t per = (exact + nt - 1) / nt;
+					const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
+					parallel_for(nt, nt, [&](int t) {
+						const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
+						if (lo < hi) memcpy(h_out + at + lo, stg + lo, hi - lo);
+					});
+				}
 				for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
 				g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
 				if (getenv("CCT_TRACE"))

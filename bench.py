@@ -131,7 +131,8 @@ def main():
     NSET = 2
     d_back = [cct_hip.DeviceBuffer(batches[0].nbytes) for _ in range(NSET)]
     arch_cap = n * out_stride
-    h_arch = [np.empty(arch_cap, dtype=np.uint8) for _ in range(NSET)]   # .cct files back to back (archive layout)
+    h_arch_pin = [cct_hip.PinnedArray(arch_cap) for _ in range(NSET)]   # page-locked: D2H / H2D without staging
+    h_arch = [p.array for p in h_arch_pin]                                # .cct files back to back (archive layout)
     h_offs = [np.zeros(n + 1, dtype=np.uint64) for _ in range(NSET)]
     h_sizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
     h_psizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]

@@ -83,6 +83,10 @@ int cct_device_info(char *name, size_t name_cap, int *compute_units, uint64_t *h
 
 int cct_dev_alloc(void **d_ptr, size_t bytes);
 int cct_dev_free(void *d_ptr);
+/* page-locked host memory: archives / file buffers allocated here are copied to and from the device without a
+ * staging pass (the batch entry points detect it); plain malloc'ed buffers keep working */
+int cct_host_alloc(void **h_ptr, size_t bytes);
+int cct_host_free(void *h_ptr);
 int cct_h2d(void *d_dst, const void *h_src, size_t bytes);
 int cct_d2h(void *h_dst, const void *d_src, size_t bytes);
 int cct_dev_memset(void *d_dst, int value, size_t bytes);

@@ -86,6 +86,16 @@ def test_packed_archive_output_equals_strided_output(hip):
     st = np.zeros(n, dtype=np.uint32)
     _ffi.check(L.cct_decode_batch(arch.ctypes.data, offs.ctypes.data, n, bs, magic, out.ctypes.data, 0, out.size, st.ctypes.data))
     assert np.array_equal(out, imgs)
+    # the same through a page-locked archive (cct_host_alloc): copied without the staging pass, same bytes
+    pin = hip.PinnedArray(cap)
+    offs2 = np.zeros(n + 1, dtype=np.uint64)
+    _ffi.check(L.cct_encode_batch_packed(imgs.ctypes.data, 0, n, w, h, bs, flags, eof, magic, ch, bpc, pin.array.ctypes.data, cap,
+                                         offs2.ctypes.data, sizes.ctypes.data, status.ctypes.data, None, None))
+    assert np.array_equal(offs2, offs) and np.array_equal(pin.array[:int(offs[n])], arch[:int(offs[n])])
+    out2 = np.empty((n, w, h), dtype=np.uint16)
+    _ffi.check(L.cct_decode_batch(pin.array.ctypes.data, offs2.ctypes.data, n, bs, magic, out2.ctypes.data, 0, out2.size, st.ctypes.data))
+    assert np.array_equal(out2, imgs)
+    pin.free()
 
 
 def _decode_both(hip, files, cfg):
