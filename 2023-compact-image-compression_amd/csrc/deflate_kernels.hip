@@ -59,7 +59,8 @@ struct MatchRec { uint16_t len4096, len1024, dist4096, dist1024; };
 // per slice walks its slice tile by tile with running digit offsets in LDS, so there is no cross-workgroup
 // scan: pass A hashes the input on the fly (value = position = index) and also counts pass B's digits.
 // Per tile: wave-level match-any gives each lane its rank among the equal digits of its wave, the 16 per-wave
-// counts are prefix-summed per digit, and lanes scatter to offset[digit] + wave prefix + rank.
+// counts are prefix-summed per digit, and lanes scatter to offset[digit] + wave prefix + rank.  All waves of a
+// slice write the same 256 (128) output streams tile after tile, which keeps the partially written lines in L2.
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would serialise the
 // scattered stores of a tile with its barriers
 __device__ __forceinline__ void lds_barrier()
@@ -108,26 +109,48 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		for (int k = 0; k < 4; k++) { offs[lane * 4 + k] = run; run += v[k]; }
 	}
 	__syncthreads();
-	for (uint32_t t0 = 0; t0 < npos; t0 += 1024) {
-		const uint32_t idx = t0 + tid;
-		const bool valid = idx < npos;
-		uint32_t h = 0, p = idx;
-		if (valid) {
+	// A tile = 4096 elements: wave w owns elements [t0 + 256 w, t0 + 256 w + 256) and ranks them in four rounds of
+	// 64 (running per-digit counts in its own LDS row), so the cross-wave prefix and its two barriers are paid
+	// once per 4096 elements.  Loads of the next tile are issued before the current one is ranked.
+	constexpr int E = 4;
+	auto fetch = [&](uint32_t idx, uint32_t &h, uint32_t &p) {
+		h = 0; p = idx;
+		if (idx < npos) {
 			if (FIRST) h = (((uint32_t)in[idx] << 10) ^ ((uint32_t)in[idx + 1] << 5) ^ in[idx + 2]) & 0x7FFFu;
 			else { h = keys_src[idx]; p = vals_src[idx]; }
 		}
-		const uint32_t d = FIRST ? (h & 255u) : (h >> 8);
-		for (int k = lane; k < NB; k += 64) wcnt[wave][k] = 0;
-		uint64_t same = __ballot(valid);  // lanes of this wave with the same digit
+	};
+	uint32_t hn[E], pn[E];
 #pragma unroll
-		for (int b = 0; b < BITS; b++) {
-			const bool bit = (d >> b) & 1u;
-			const uint64_t bal = __ballot(bit);
-			same &= bit ? bal : ~bal;
+	for (int e = 0; e < E; e++) fetch((uint32_t)(wave * 64 * E + e * 64 + lane), hn[e], pn[e]);
+	for (uint32_t t0 = 0; t0 < npos; t0 += 1024 * E) {
+		uint32_t h[E], p[E], rk[E];
+		const uint32_t idx0 = t0 + (uint32_t)(wave * 64 * E + lane);
+#pragma unroll
+		for (int e = 0; e < E; e++) { h[e] = hn[e]; p[e] = pn[e]; }
+#pragma unroll
+		for (int e = 0; e < E; e++) fetch(idx0 + 1024 * E + e * 64, hn[e], pn[e]);
+		for (int k = lane; k < NB; k += 64) wcnt[wave][k] = 0;
+#pragma unroll
+		for (int e = 0; e < E; e++) {
+			const bool valid = idx0 + e * 64 < npos;
+			const uint32_t d = FIRST ? (h[e] & 255u) : (h[e] >> 8);
+			uint64_t same = __ballot(valid);  // lanes of this round with the same digit
+#pragma unroll
+			for (int b = 0; b < BITS; b++) {
+				const bool bit = (d >> b) & 1u;
+				const uint64_t bal = __ballot(bit);
+				same &= bit ? bal : ~bal;
+			}
+			const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
+			uint32_t before = 0;
+			if (valid) {
+				before = wcnt[wave][d];  // equal digits of this wave's earlier rounds
+				if (rank == 0) wcnt[wave][d] = before + (uint32_t)__popcll(same);
+				if (FIRST) atomicAdd(&next_hist[h[e] >> 8], 1u);
+			}
+			rk[e] = before + rank;
 		}
-		const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
-		if (valid && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);
-		if (FIRST && valid) atomicAdd(&next_hist[h >> 8], 1u);
 		lds_barrier();
 		if (tid < NB) {  // running offset of digit tid, handed out wave by wave
 			uint32_t c[16], run = offs[tid];
@@ -138,10 +161,14 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			offs[tid] = run;
 		}
 		lds_barrier();
-		if (valid) {
-			const uint32_t dst = wcnt[wave][d] + rank;
-			keys_dst[dst] = (uint16_t)h;
-			vals_dst[dst] = p;
+#pragma unroll
+		for (int e = 0; e < E; e++) {
+			if (idx0 + e * 64 < npos) {
+				const uint32_t d = FIRST ? (h[e] & 255u) : (h[e] >> 8);
+				const uint32_t dst = wcnt[wave][d] + rk[e];
+				keys_dst[dst] = (uint16_t)h[e];
+				vals_dst[dst] = p[e];
+			}
 		}
 	}
 	if (FIRST) {
