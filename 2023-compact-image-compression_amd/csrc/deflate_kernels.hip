@@ -322,15 +322,19 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 			// strings that START a run of three equal bytes share one bucket with every other position of
 			// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
 			// the list of run ends instead of walking the chain
-			const uint32_t rw = rl[p];
-			const uint32_t run_r = rw & 0x7FFFu;  // <= max_len by construction
-			if (run_r >= 3) {
+			// the first 8 bytes of the string decide most things; in hash order every access to the slice is its own
+			// L2 transaction, so the run-length word is only fetched for the strings that need it
+			const bool wide = p + 8 <= L;  // then max_len >= 8 and sp[0..7] is inside the input
+			uint64_t ow = 0;
+			if (wide) __builtin_memcpy(&ow, sp, 8);
+			const bool in_run = wide ? (((ow >> 8) ^ ow) & 0xFFFFu) == 0 : (sp[1] == sp[0] && sp[2] == sp[0]);
+			uint32_t run_r = 0;
+			if (in_run) {
+				const uint32_t rw = rl[p];
+				run_r = rw & 0x7FFFu;  // >= 3, <= max_len by construction
 				if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
 				else kind = 2;
 			} else {
-				const bool wide = p + 8 <= L;  // then max_len >= 8 and sp[0..7] is inside the input
-				uint64_t ow = 0;
-				if (wide) __builtin_memcpy(&ow, sp, 8);
 				for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
 					if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
 					const uint32_t q = vals[j];
