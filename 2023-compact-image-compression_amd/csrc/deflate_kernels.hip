@@ -797,7 +797,10 @@ struct TreeScratch {  // one block's working set, in LDS
 	uint8_t extra_l[29], extra_d[30], extra_bl[19], bl_order[19], static_llen[L_CODES + 2], length_code[256], dist_code[512];
 };
 
-struct TreeView { uint16_t *freq, *dad, *len, *code; };
+// LDS-typed pointers: a view chosen at run time (one copy of the tree code serves all three alphabets) still
+// compiles to ds_* instructions
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+struct TreeView { lds_u16 *freq, *dad, *len, *code; };
 
 __device__ __forceinline__ void pqdownheap(TreeScratch &S, int k)
 {
@@ -1050,14 +1053,25 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 	__syncthreads();
 	if (threadIdx.x == 0) S.freq[END_BLOCK] = 1;
 	__syncthreads();
-	const TreeView lt{S.freq, S.dad, S.len, S.code}, dt{S.dfreq, S.ddad, S.dlen, S.dcode}, btv{S.bfreq, S.bdad, S.blen, S.bcode};
-	const int lmax = build_tree(S, lt, 0);
-	const int dmax = build_tree(S, dt, 1);
-	const uint32_t dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
-	__syncthreads();
-	if (threadIdx.x == 0) { scan_tree(S, lt, lmax); scan_tree(S, dt, dmax); }
-	__syncthreads();
-	build_tree(S, btv, 2);
+	const TreeView lt{(lds_u16 *)S.freq, (lds_u16 *)S.dad, (lds_u16 *)S.len, (lds_u16 *)S.code};
+	const TreeView dt{(lds_u16 *)S.dfreq, (lds_u16 *)S.ddad, (lds_u16 *)S.dlen, (lds_u16 *)S.dcode};
+	const TreeView btv{(lds_u16 *)S.bfreq, (lds_u16 *)S.bdad, (lds_u16 *)S.blen, (lds_u16 *)S.bcode};
+	int lmax = 0, dmax = 0;
+	uint32_t dyn_body_bits = 0;
+#pragma unroll 1
+	for (int kind = 0; kind < 3; kind++) {  // literal/length, distance, then the bit-length tree over both
+		if (kind == 2) {
+			dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
+			__syncthreads();
+			if (threadIdx.x == 0) {
+#pragma unroll 1
+				for (int w = 0; w < 2; w++) scan_tree(S, w ? dt : lt, w ? dmax : lmax);
+			}
+			__syncthreads();
+		}
+		const int mc = build_tree(S, kind == 0 ? lt : kind == 1 ? dt : btv, kind);
+		if (kind == 0) lmax = mc; else if (kind == 1) dmax = mc;
+	}
 	if (threadIdx.x == 0) {
 		int max_blindex;
 		for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
@@ -1081,8 +1095,8 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 			hdr_put(S, (uint32_t)(dmax + 1 - 1), 5);
 			hdr_put(S, (uint32_t)(max_blindex + 1 - 4), 4);
 			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[S.bl_order[rank]], 3);
-			send_tree(S, lt, lmax);
-			send_tree(S, dt, dmax);
+#pragma unroll 1
+			for (int w = 0; w < 2; w++) send_tree(S, w ? dt : lt, w ? dmax : lmax);
 			bm.hdr_nbits = S.hdr_nbits;
 			bm.body_bits = dyn_body_bits;
 		}
