@@ -83,6 +83,12 @@ struct Context {
 	hipStream_t stream_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipEvent_t ev_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	hipEvent_t ev_zfork = nullptr;
+	// packed archives leave the device on their own stream from one of two buffers, after the device lock has
+	// been released: the next encode call may start its kernels while this one's files are still on the wire
+	hipStream_t stream_copy = nullptr;
+	hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+	DevBuf z_packed2[2];
+	unsigned pack_slot = 0;
 	int deflate_ways = 1;  // option "deflate_ways" (1..8): 2 is ~8 % faster alone but unstable next to a concurrent decode stream
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
@@ -507,7 +513,7 @@ int cct_shutdown(void)
 	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage,
 	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
 	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
-	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs};
+	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs, &g_ctx.z_packed2[0], &g_ctx.z_packed2[1]};
 	for (DevBuf *b : bufs) b->release();
 	(void)hipEventDestroy(g_ctx.ev_k0);
 	(void)hipEventDestroy(g_ctx.ev_k1);
@@ -689,7 +695,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	// h_packed_offsets != NULL: archive layout -- files back to back in h_out (capacity out_stride bytes in
 	// total), h_packed_offsets[n+1]; needs the device DEFLATE path (or deflate off)
 	const bool packed = h_packed_offsets != nullptr;
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::unique_lock<std::mutex> lk(g_mu);
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
@@ -768,6 +774,40 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				if (c0 == 0) h_packed_offsets[0] = 0;
 				const uint64_t at = h_packed_offsets[c0];
 				if (at + exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + exact));
+				if (nc == n && is_pinned_host(h_out + at, exact)) {
+					// whole batch in one pass into a page-locked archive: pack into one of two device buffers, hand the
+					// copy to the copy stream and give the device lock back before waiting for it
+					const unsigned slot = g_ctx.pack_slot++ & 1u;
+					if (!g_ctx.stream_copy) {
+						HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_copy, hipStreamNonBlocking));
+						for (int k = 0; k < 2; k++) {
+							HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_pack[k], hipEventDisableTiming));
+							HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_copied[k], hipEventDisableTiming));
+							HIP_TRY(hipEventRecord(g_ctx.ev_copied[k], g_ctx.stream_copy));
+						}
+					}
+					if (g_ctx.z_packed2[slot].cap < packed_cap + 16) HIP_TRY(hipEventSynchronize(g_ctx.ev_copied[slot]));  // about to be reallocated
+					if ((rc = g_ctx.z_packed2[slot].ensure(packed_cap + 16))) return rc;
+					HIP_TRY(hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
+					HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
+					                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed2[slot].p, 1, g_ctx.stream));
+					HIP_TRY(hipEventRecord(g_ctx.ev_pack[slot], g_ctx.stream));
+					HIP_TRY(hipStreamWaitEvent(g_ctx.stream_copy, g_ctx.ev_pack[slot], 0));
+					HIP_TRY(hipMemcpyAsync(h_out + at, g_ctx.z_packed2[slot].p, exact, hipMemcpyDeviceToHost, g_ctx.stream_copy));
+					HIP_TRY(hipEventRecord(g_ctx.ev_copied[slot], g_ctx.stream_copy));
+					hipEvent_t done = g_ctx.ev_copied[slot];
+					for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
+					if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
+					const float t_defl = g_ctx.t_dev_deflate_ms;
+					lk.unlock();
+					HIP_TRY(hipEventSynchronize(done));
+					const float t_tail = (float)(now_ms() - t_c0);
+					if (getenv("CCT_TRACE"))
+						fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h (lock released) %.2f ms (%zu bytes)\n", nc, t_defl, t_tail, exact);
+					lk.lock();
+					g_ctx.t_d2h_ms = t_tail;
+					return CCT_OK;
+				}
 				HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
 				                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 1, g_ctx.stream));
 				double t_c1;

@@ -128,7 +128,7 @@ def main():
     # Two buffer sets: while step k is decoded (host INFLATE + decode kernel) step k+1 is already being
     # encoded (transform+pack + device DEFLATE).  Two host threads drive the C ABI; ctypes drops the GIL.
     out_stride = L.cct_file_bound(W, H, bs)
-    NSET = 2
+    NSET = 3
     d_back = [cct_hip.DeviceBuffer(batches[0].nbytes) for _ in range(NSET)]
     arch_cap = n * out_stride
     h_arch_pin = [cct_hip.PinnedArray(arch_cap) for _ in range(NSET)]   # page-locked: D2H / H2D without staging
@@ -140,7 +140,9 @@ def main():
     acc = {"enc_kernel": 0.0, "d2h": 0.0, "deflate": 0.0, "inflate": 0.0, "dec_kernel": 0.0, "enc": 0.0, "dec": 0.0,
            "gather": 0.0, "payload_bytes": 0, "file_bytes": 0}
     from concurrent.futures import ThreadPoolExecutor
-    pool_enc, pool_dec = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
+    # two encode threads: the library gives the device lock back while a batch's files are still on the wire, so
+    # the next batch's kernels start during that copy
+    pool_enc, pool_dec = ThreadPoolExecutor(2 if not args.no_overlap else 1), ThreadPoolExecutor(1)
     overlap = not args.no_overlap
 
     def enc_step(i, k, record):
@@ -171,17 +173,25 @@ def main():
     state = {"sizes": None}
 
     def run_steps(first, count, record):
+        prev = None  # (future, set) of the previous encode
         for i in range(first, first + count):
             k = i % NSET
             while len(in_flight) >= (NSET if overlap else 1):
                 in_flight.pop(0).result()       # buffer set k is free again
             e = pool_enc.submit(enc_step, i, k, record)
             in_flight.append(pool_dec.submit(dec_step, k, e, record))
-            e.result()
-            t1 = time.perf_counter()
-            state["sizes"] = gather_sizes(h_sizes[k], dist, local_rank)  # RCCL all-gather of compressed sizes
-            if record:
-                acc["gather"] += (time.perf_counter() - t1) * 1e3
+            if not overlap:
+                prev = (e, k)
+            if prev is not None:                # at most two encodes in flight
+                prev[0].result()
+                t1 = time.perf_counter()
+                state["sizes"] = gather_sizes(h_sizes[prev[1]], dist, local_rank)  # RCCL all-gather of compressed sizes
+                if record:
+                    acc["gather"] += (time.perf_counter() - t1) * 1e3
+            prev = None if not overlap else (e, k)
+        if prev is not None:
+            prev[0].result()
+            state["sizes"] = gather_sizes(h_sizes[prev[1]], dist, local_rank)
         while in_flight:
             in_flight.pop(0).result()
 
@@ -254,6 +264,8 @@ def main():
                 "deflate": "device (deflate_kernels.hip, byte-identical to zlib 1.2.11 level 9)" if dev_deflate.value
                 else "host libz thread team", "inflate": "device (inflate_kernels.hip, speculative lane-parallel decode)" if dev_inflate.value
                 else "host libz thread team",
+                "note": "enc/dec = wall time of the C calls; with overlap two encode calls are in flight, so enc includes "
+                        "the wait for the device lock",
                 "host_threads": zthreads, "host_cpus": ncpu,
                 "compression_ratio": round(2.0 * npx * K / max(1, acc["file_bytes"]), 4)},
             "device": info["name"], "verified": verified,
