@@ -66,6 +66,7 @@ _SIGS = {
                                           C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "cct_zlib_compress_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cct_zlib_decompress_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "cct_read_header": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(Header)]),
     "cct_decode_payload_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]),

@@ -258,3 +258,26 @@ def zlib_compress_batch(blobs):
     sizes = np.zeros(n, dtype=np.uint32)
     _ffi.check(L.cct_zlib_compress_batch(data, offs.ctypes.data, n, out.ctypes.data, out_stride, sizes.ctypes.data))
     return [out[i, : sizes[i]].tobytes() for i in range(n)]
+
+
+def zlib_decompress_batch(streams, max_out, raise_errors=True):
+    """INFLATE stage alone on the device: [zlib streams] -> [bytes], what zlib.decompress returns for each
+    (the reference calls it at core.py:421).  max_out bounds the inflated size of one stream.  With
+    raise_errors=False returns (outputs, status) where status[i] is 0, CCT_E_ZLIB (2) or CCT_E_CAP (6)."""
+    L = _ffi.lib()
+    n = len(streams)
+    if n == 0:
+        return [] if raise_errors else ([], np.zeros(0, dtype=np.uint32))
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in streams], out=offs[1:])
+    data = b"".join(streams) or b"\0"
+    out_stride = (int(max_out) + 15 + 16) & ~15
+    out = np.empty((n, out_stride), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.uint32)
+    rc = L.cct_zlib_decompress_batch(data, offs.ctypes.data, n, out.ctypes.data, out_stride, sizes.ctypes.data,
+                                     status.ctypes.data)
+    if raise_errors:
+        _ffi.check(rc)
+    outs = [out[i, : sizes[i]].tobytes() if status[i] == 0 else None for i in range(n)]
+    return outs if raise_errors else (outs, status)

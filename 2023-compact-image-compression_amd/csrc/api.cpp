@@ -937,6 +937,59 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
 	return CCT_OK;
 }
 
+int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, uint8_t *h_out, size_t out_stride,
+                              uint32_t *h_out_sizes, uint32_t *h_status)
+{
+	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
+	if (out_stride == 0 || (out_stride & 15)) return fail(CCT_E_ARG, "out_stride must be a positive multiple of 16");
+	if (!(g_ctx.ready && g_ctx.pid == getpid())) {
+		std::lock_guard<std::mutex> lk(g_mu);
+		int rc0 = ensure_ctx();
+		if (rc0) return rc0;
+	}
+	if (n == 0) return CCT_OK;
+	int rc;
+	HIP_TRY(hipSetDevice(g_ctx.device));
+	const uint64_t a0 = h_offsets[0], a1 = h_offsets[n];
+	const size_t abytes = (size_t)(a1 - a0), apad = (abytes + 31) & ~(size_t)15;
+	if ((rc = g_ctx.d_arch.ensure(apad + 16))) return rc;
+	if ((rc = g_ctx.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
+	if ((rc = g_ctx.d_zstatus.ensure((size_t)n * 4))) return rc;
+	if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = g_ctx.d_payload.ensure((size_t)n * out_stride))) return rc;
+	std::vector<uint64_t> rel(n + 1);
+	for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
+	hipStream_t st = g_ctx.stream_dec;
+	HIP_TRY(hipMemsetAsync((uint8_t *)g_ctx.d_arch.p + (apad > 32 ? apad - 32 : 0), 0, apad > 32 ? 48 : apad + 16, st));
+	if (abytes) HIP_TRY(hipMemcpyAsync(g_ctx.d_arch.p, h_in + a0, abytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(g_ctx.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	InflateArgs ia{};
+	ia.in = (const uint8_t *)g_ctx.d_arch.p; ia.in_total = apad;
+	ia.offsets = (const uint64_t *)g_ctx.d_archoffs.p; ia.skip = 0;
+	ia.out = (uint8_t *)g_ctx.d_payload.p; ia.out_stride = out_stride;
+	ia.out_sizes = (uint32_t *)g_ctx.d_sizes.p; ia.status = (uint32_t *)g_ctx.d_zstatus.p;
+	HIP_TRY(launch_inflate(ia, n, st));
+	std::vector<uint32_t> zst(n), osz(n);
+	HIP_TRY(hipMemcpyAsync(zst.data(), g_ctx.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	int first = CCT_OK;
+	for (int i = 0; i < n; i++) {
+		h_status[i] = (zst[i] & CCT_ST_ZLIB) ? CCT_E_ZLIB : (zst[i] & CCT_ST_STREAM) ? CCT_E_CAP : CCT_OK;
+		h_out_sizes[i] = h_status[i] == CCT_OK ? osz[i] : 0;
+		if (h_status[i] == CCT_OK && osz[i])
+			HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.d_payload.p + (size_t)i * out_stride, osz[i],
+			                       hipMemcpyDeviceToHost, st));
+		if (h_status[i] != CCT_OK && first == CCT_OK) {
+			first = (int)h_status[i];
+			fail(first, "stream %d: %s", i, first == CCT_E_ZLIB ? "invalid DEFLATE stream" : "output larger than out_stride");
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	return first;
+}
+
 int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_header *out)
 {
 	if (!h_file || !out) return fail(CCT_E_ARG, "null argument");

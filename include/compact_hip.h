@@ -155,6 +155,15 @@ int cct_encode_batch_packed(const uint16_t *images, int images_on_device, int n,
 int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n,
                             uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes);
 
+/* INFLATE stage alone, on the device: n zlib streams (h_in[h_offsets[i] .. h_offsets[i+1])) -> the bytes
+ * zlib.decompress returns for each (what the reference calls at core.py:421).  Output i lands at
+ * h_out + i*out_stride (out_stride a multiple of 16); h_status[i] = CCT_OK, CCT_E_ZLIB (anything libz
+ * rejects: bad header, invalid code, distance too far back, truncated stream, Adler-32 mismatch) or
+ * CCT_E_CAP (the stream inflates to more than out_stride bytes).  Returns the first non-OK status.
+ * Option "device_inflate" (default 1) selects this implementation inside cct_decode_batch. */
+int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n,
+                              uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status);
+
 /* ---- decode ----------------------------------------------------------------------- */
 /* Replaces Decoder.read_header (core.py:385-402). */
 int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_header *out);

@@ -160,3 +160,59 @@ def test_device_inflate_rejects_bad_streams_like_zlib(hip):
                     hip.decode_batch([blob], cfg)
             finally:
                 _ffi.check(_ffi.lib().cct_set_option(b"device_inflate", 1))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device INFLATE on arbitrary data (cct_zlib_decompress_batch): everything libz can write must come back
+def _rng_bytes(seed, n, alphabet):
+    return np.random.default_rng(seed).integers(0, alphabet, n, dtype=np.uint8).tobytes()
+
+
+def _inflate_cases():
+    import zlib as z
+    blobs = {
+        "empty": b"", "one": b"a", "zeros_1M": bytes(1 << 20), "zeros_258": bytes(258), "ab_rep": b"ab" * 50000,
+        "random_64k": _rng_bytes(1, 65536, 256), "random_300k_a4": _rng_bytes(2, 300000, 4),
+        "text_like": (b"the quick brown fox jumps over the lazy dog. " * 4000),
+        "runs_mixed": b"".join(bytes([i % 7]) * (i % 300 + 1) for i in range(3000)),
+        "far_matches": _rng_bytes(3, 32768, 256) * 6,
+    }
+    cases = []
+    for name, b in blobs.items():
+        for level in (1, 6, 9):
+            cases.append((f"{name}_l{level}", z.compress(b, level), b))
+        for strat, sname in ((z.Z_FIXED, "fixed"), (z.Z_RLE, "rle"), (z.Z_HUFFMAN_ONLY, "huff"), (z.Z_FILTERED, "filt")):
+            c = z.compressobj(9, z.DEFLATED, 15, 9, strat)
+            cases.append((f"{name}_{sname}", c.compress(b) + c.flush(), b))
+        c = z.compressobj(0)
+        cases.append((f"{name}_stored", c.compress(b) + c.flush(), b))
+        c = z.compressobj(6, z.DEFLATED, 9)  # 512-byte window
+        cases.append((f"{name}_w9", c.compress(b) + c.flush(), b))
+        c = z.compressobj(6)  # several flush points: empty stored blocks and block boundaries everywhere
+        parts = [c.compress(b[i:i + 7001]) + c.flush(z.Z_SYNC_FLUSH) for i in range(0, len(b), 7001)]
+        cases.append((f"{name}_syncflush", b"".join(parts) + c.flush(), b))
+    return cases
+
+
+def test_device_inflate_alone_matches_zlib_on_many_encoders(hip):
+    cases = _inflate_cases()
+    outs = hip.zlib_decompress_batch([c[1] for c in cases], max_out=max(len(c[2]) for c in cases))
+    for (name, _, want), got in zip(cases, outs):
+        assert got == want, name
+
+
+def test_device_inflate_alone_reports_errors_per_stream(hip):
+    import zlib as z
+    good = z.compress(b"hello world" * 1000, 9)
+    bad_adler = good[:-1] + bytes([good[-1] ^ 1])
+    truncated = good[: len(good) // 2]
+    bad_header = b"\x78\x9b" + good[2:]
+    too_long = z.compress(bytes(100000), 9)
+    garbage = _rng_bytes(9, 500, 256)
+    outs, status = hip.zlib_decompress_batch([good, bad_adler, truncated, bad_header, too_long, garbage, good], max_out=20000,
+                                             raise_errors=False)
+    assert list(status[:4]) == [0, 2, 2, 2] and status[4] == 6 and status[5] == 2 and status[6] == 0  # CCT_E_ZLIB = 2, CCT_E_CAP = 6
+    assert outs[0] == outs[6] == b"hello world" * 1000
+    for s_ in (bad_adler, truncated, bad_header, garbage):
+        with pytest.raises(z.error):
+            z.decompress(s_)
