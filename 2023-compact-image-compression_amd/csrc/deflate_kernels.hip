@@ -743,14 +743,21 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 		const uint32_t k = rec & 0xFFu, len = (rec >> 8) & 0x1FFu, dist = rec >> 17;
 		const uint32_t nxt = len ? p + k + len : p + 1;
 		const uint32_t cnt = len ? k + 1 : 1;
-		// which lanes are decision positions: follow next from the entry (wave-uniform loop)
+		// which lanes are decision positions: a literal position hands over to its neighbour, so the chain from the
+		// entry covers whole stretches of lanes up to the next position that starts a match, and only the matches
+		// need a hop (wave-uniform loop on the scalar unit)
+		const uint64_t jump = __ballot(len != 0);
+		const uint32_t nvalid = min(64u, L - wb * 64);
 		uint64_t visited = 0;
-		uint32_t cur = entry;
-		while (cur < wb * 64 + 64 && cur < L) {
-			const int j = __builtin_amdgcn_readfirstlane((int)(cur - wb * 64));
-			visited |= 1ull << j;
-			cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt, j);
+		uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(entry - wb * 64));
+		while (cur < nvalid) {
+			const uint64_t rest = jump >> cur;
+			if (!rest) { visited |= ~0ull << cur; break; }
+			const int d = __ffsll((long long)rest) - 1;  // lanes cur .. cur + d are visited, the last one jumps
+			visited |= (d >= 63 ? ~0ull : ((2ull << d) - 1ull)) << cur;
+			cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur + d) - wb * 64;
 		}
+		if (nvalid < 64) visited &= (1ull << nvalid) - 1ull;
 		const bool mine = (visited >> lane) & 1ull;
 		// exclusive prefix of symbol counts over the visited lanes
 		uint32_t v = mine ? cnt : 0u, inc = v;
