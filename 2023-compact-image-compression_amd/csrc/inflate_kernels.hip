@@ -6,7 +6,7 @@
 // One workgroup of 4 waves per stream.  The format carries no symbol index, so the position of symbol k+1 is
 // only known after symbol k has been decoded; a single lane walking that chain spends ~10^3 cycles per symbol.
 // The workgroup breaks the chain speculatively (Huffman codes re-synchronise after a few symbols):
-//   * a round covers 256 segments of SEG_BITS compressed bits, one per lane; lane 0 starts at the true position,
+//   * a round covers 256 segments of SEG_BITS (256) compressed bits, one per lane; lane 0 starts at the true position,
 //     the others at their segment boundary, and every lane decodes until it crosses into the next segment;
 //   * lanes then restart from where their predecessor really landed until no start moves any more (lane k is
 //     final after k passes at the latest; in practice 2-3 passes), which yields the true chain of the round;
@@ -34,10 +34,11 @@ constexpr int INF_IN = 16384, INF_CHUNK = 4096;
 constexpr int LL_BITS = 11, D_BITS = 10;
 constexpr int LL_SUB = 1280, D_SUB = 256;     // a complete sub-tree of depth 4 has >= 5 leaves: <= 16/5 entries per long code
 constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24;
-constexpr int SEG_BITS = 128;                 // compressed bits per lane and round
-constexpr int ROUND_OUT_BUDGET = 24576;       // output bytes of a round (lane 0 alone: at most SEG_BITS / 2 * 258 = 16512)
-constexpr int MLIST_CAP = 2048;               // LZ77 copies a round may hold (lane 0 alone: at most SEG_BITS / 2)
-constexpr uint32_t SEG_EOB = 1, SEG_BAD = 2;
+constexpr int SEG_BITS = 256;                 // compressed bits per lane and round
+constexpr int ROUND_OUT_BUDGET = 24576;       // output bytes of a round
+constexpr int LANE_OUT_CAP = 16384;           // a lane stops (and ends the round) once it has produced this much
+constexpr int MLIST_CAP = 2048;               // LZ77 copies a round may hold (one lane alone: at most SEG_BITS / 2)
+constexpr uint32_t SEG_EOB = 1, SEG_BAD = 2, SEG_CUT = 4;
 
 __constant__ uint16_t c_lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 __constant__ uint8_t c_lext[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -265,6 +266,7 @@ __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, u
 	lane_init(S, lb, org_dword, start);
 	nbytes = 0; nmatch = 0; flags = 0;
 	while (lane_pos(lb, org_dword) < end) {
+		if (nbytes >= (uint32_t)LANE_OUT_CAP) { flags = SEG_CUT; break; }  // keeps a round inside the output ring
 		lane_refill(S, lb);
 		uint32_t lo = (uint32_t)lb.buf;
 		uint32_t e = S.ll_tab[lo & ((1u << LL_BITS) - 1u)];
