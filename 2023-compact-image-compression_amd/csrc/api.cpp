@@ -85,6 +85,12 @@ struct Context {
 	hipEvent_t ev_zfork = nullptr;
 	// packed archives leave the device on their own stream from one of two buffers, after the device lock has
 	// been released: the next encode call may start its kernels while this one's files are still on the wire
+	// the ~25 launches of one DEFLATE pass, captured once per argument set and replayed as a graph: fewer host
+	// calls and no dispatch gaps between the kernels when a decode shares the queue processor
+	hipGraph_t z_graph = nullptr;
+	hipGraphExec_t z_graph_exec = nullptr;
+	std::vector<uint8_t> z_graph_key;
+	int use_graph = 1;
 	hipStream_t stream_copy = nullptr;
 	hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
 	DevBuf z_packed2[2];
@@ -438,6 +444,25 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.max_blocks = max_blocks;
 	a.out = (uint8_t *)g_ctx.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)g_ctx.z_outsizes.p;
 	memcpy(a.header13, header13, 13);
+	if (ways == 1 && g_ctx.use_graph) {
+		// whole batch on the main stream, as a graph keyed by everything the launches depend on
+		std::vector<uint8_t> key(sizeof(DeflateArgs) + sizeof(int));
+		memcpy(key.data(), &a, sizeof(DeflateArgs));
+		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
+		if (!g_ctx.z_graph_exec || key != g_ctx.z_graph_key) {
+			if (g_ctx.z_graph_exec) { (void)hipGraphExecDestroy(g_ctx.z_graph_exec); g_ctx.z_graph_exec = nullptr; }
+			if (g_ctx.z_graph) { (void)hipGraphDestroy(g_ctx.z_graph); g_ctx.z_graph = nullptr; }
+			HIP_TRY(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
+			hipError_t le = launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream);
+			hipError_t ce = hipStreamEndCapture(g_ctx.stream, &g_ctx.z_graph);
+			if (le != hipSuccess) return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le));
+			HIP_TRY(ce);
+			HIP_TRY(hipGraphInstantiate(&g_ctx.z_graph_exec, g_ctx.z_graph, nullptr, nullptr, 0));
+			g_ctx.z_graph_key = key;
+		}
+		HIP_TRY(hipGraphLaunch(g_ctx.z_graph_exec, g_ctx.stream));
+		return CCT_OK;
+	}
 	HIP_TRY(hipEventRecord(g_ctx.ev_zfork, g_ctx.stream));  // inputs are produced on the main stream
 	for (int w = 0; w < ways; w++) {
 		const int s0 = w * per_way, ns = std::min(per_way, n - s0);
@@ -1173,6 +1198,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { if (value < 1 || value > 8) return fail(CCT_E_ARG, "deflate_ways must be 1..8"); g_ctx.deflate_ways = value; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
@@ -1188,6 +1214,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
+	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }
