@@ -428,23 +428,43 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			// the code lengths of both alphabets, run-length coded; S.lens is reused after cl is built
 			int idx = 0;
 			uint8_t prev_len = 0;
-			while (idx < nlen + ndist) {
-				refill(S, br);
-				const uint32_t ce = S.cl_tab[br.buf & ((1u << CL_BITS) - 1u)];
-				if (ce == 0) { err = CCT_ST_ZLIB; break; }
-				getbits(br, (int)(ce & 7u));
-				const int sym = (int)(ce >> 3);
-				if (sym < 16) { if (tid == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
-				else {
-					int rep; uint8_t v = 0;
-					if (sym == 16) { if (idx == 0) { err = CCT_ST_ZLIB; break; } v = prev_len; rep = 3 + (int)getbits(br, 2); }
-					else if (sym == 17) rep = 3 + (int)getbits(br, 3);
-					else rep = 11 + (int)getbits(br, 7);
-					if (idx + rep > nlen + ndist) { err = CCT_ST_ZLIB; break; }
-					for (int t = tid; t < rep; t += NT) S.lens[idx + t] = v;
-					idx += rep;
-					if (sym != 16) prev_len = 0;
+			{
+				// This loop is one dependent chain of ~316 table lookups.  Every lane holds the same reader state, but
+				// in vector registers; readfirstlane moves it to the scalar unit, whose dependent operations cost a
+				// cycle or two instead of a vector-pipeline pass each.
+				while (br.bytepos + 1024 > br.staged_end) stage_chunk(S, br);  // the header is < 700 bytes
+				const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
+				uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(br.buf >> 32)) << 32) |
+				              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)br.buf);
+				int sc = __builtin_amdgcn_readfirstlane(br.cnt);
+				uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(br.bytepos >> 2));  // next dword
+				const uint32_t sw0 = sw;
+				const int total = nlen + ndist;
+				while (idx < total) {
+					if (sc < 16) {
+						const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)in32[sw & (INF_IN / 4 - 1)]);
+						sb |= (uint64_t)w << sc; sc += 32; sw++;
+					}
+					const uint32_t lo = (uint32_t)sb;
+					const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.cl_tab[lo & ((1u << CL_BITS) - 1u)]);
+					if (ce == 0) { err = CCT_ST_ZLIB; break; }
+					const int sym = (int)(ce >> 3);
+					const uint32_t cbits = ce & 7u, xbits = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+					const uint32_t xval = (lo >> cbits) & ((1u << xbits) - 1u);
+					sb >>= (cbits + xbits); sc -= (int)(cbits + xbits);
+					if (sym < 16) { if (tid == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
+					else {
+						int rep; uint8_t v = 0;
+						if (sym == 16) { if (idx == 0) { err = CCT_ST_ZLIB; break; } v = prev_len; rep = 3 + (int)xval; }
+						else if (sym == 17) rep = 3 + (int)xval;
+						else rep = 11 + (int)xval;
+						if (idx + rep > total) { err = CCT_ST_ZLIB; break; }
+						for (int t = tid; t < rep; t += NT) S.lens[idx + t] = v;
+						idx += rep;
+						if (sym != 16) prev_len = 0;
+					}
 				}
+				br.buf = sb; br.cnt = sc; br.bytepos += (uint64_t)(sw - sw0) * 4u;
 			}
 			if (err) break;
 			__syncthreads();
