@@ -440,30 +440,39 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 				uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(br.bytepos >> 2));  // next dword
 				const uint32_t sw0 = sw;
 				const int total = nlen + ndist;
-				while (idx < total) {
-					if (sc < 16) {
-						const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)in32[sw & (INF_IN / 4 - 1)]);
-						sb |= (uint64_t)w << sc; sc += 32; sw++;
+				uint32_t lerr = 0;
+				if (wave == 0) {  // one wave walks the chain; the others wait at the barrier and leave their issue slots free
+					while (idx < total) {
+						if (sc < 16) {
+							const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)in32[sw & (INF_IN / 4 - 1)]);
+							sb |= (uint64_t)w << sc; sc += 32; sw++;
+						}
+						const uint32_t lo = (uint32_t)sb;
+						const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.cl_tab[lo & ((1u << CL_BITS) - 1u)]);
+						if (ce == 0) { lerr = 1; break; }
+						const int sym = (int)(ce >> 3);
+						const uint32_t cbits = ce & 7u, xbits = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+						const uint32_t xval = (lo >> cbits) & ((1u << xbits) - 1u);
+						sb >>= (cbits + xbits); sc -= (int)(cbits + xbits);
+						if (sym < 16) { if (lane == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
+						else {
+							int rep; uint8_t v = 0;
+							if (sym == 16) { if (idx == 0) { lerr = 1; break; } v = prev_len; rep = 3 + (int)xval; }
+							else if (sym == 17) rep = 3 + (int)xval;
+							else rep = 11 + (int)xval;
+							if (idx + rep > total) { lerr = 1; break; }
+							for (int t = lane; t < rep; t += 64) S.lens[idx + t] = v;
+							idx += rep;
+							if (sym != 16) prev_len = 0;
+						}
 					}
-					const uint32_t lo = (uint32_t)sb;
-					const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.cl_tab[lo & ((1u << CL_BITS) - 1u)]);
-					if (ce == 0) { err = CCT_ST_ZLIB; break; }
-					const int sym = (int)(ce >> 3);
-					const uint32_t cbits = ce & 7u, xbits = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
-					const uint32_t xval = (lo >> cbits) & ((1u << xbits) - 1u);
-					sb >>= (cbits + xbits); sc -= (int)(cbits + xbits);
-					if (sym < 16) { if (tid == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
-					else {
-						int rep; uint8_t v = 0;
-						if (sym == 16) { if (idx == 0) { err = CCT_ST_ZLIB; break; } v = prev_len; rep = 3 + (int)xval; }
-						else if (sym == 17) rep = 3 + (int)xval;
-						else rep = 11 + (int)xval;
-						if (idx + rep > total) { err = CCT_ST_ZLIB; break; }
-						for (int t = tid; t < rep; t += NT) S.lens[idx + t] = v;
-						idx += rep;
-						if (sym != 16) prev_len = 0;
-					}
+					if (lane == 0) { S.rres[0] = (uint32_t)sb; S.rres[1] = (uint32_t)(sb >> 32); S.rres[2] = (uint32_t)sc | (lerr << 16); S.rres[3] = sw; }
 				}
+				__syncthreads();
+				sb = (uint64_t)S.rres[0] | ((uint64_t)S.rres[1] << 32);
+				sc = (int)(S.rres[2] & 0xFFFFu);
+				if (S.rres[2] >> 16) err = CCT_ST_ZLIB;
+				sw = S.rres[3];
 				br.buf = sb; br.cnt = sc; br.bytepos += (uint64_t)(sw - sw0) * 4u;
 			}
 			if (err) break;
