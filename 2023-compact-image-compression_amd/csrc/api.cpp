@@ -120,7 +120,6 @@ struct Context {
 	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
 	DevBuf dh_stage;  // pinned host staging of inflated payloads (decode owns it, see g_mu_dec)
-	float t_enc_kernel_ms = 0, t_dec_kernel_ms = 0, t_d2h_ms = 0, t_deflate_ms = 0, t_inflate_ms = 0, t_h2d_ms = 0;
 };
 
 double now_ms()
@@ -130,6 +129,9 @@ double now_ms()
 }
 
 Context g_ctx;
+// timings of the calling thread's most recent batch call (cct_last_timings): per thread, so that an encode and a
+// decode driven from two threads do not overwrite each other's numbers
+thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
 std::mutex g_mu;      // device context, stream and every HIP call
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
 std::mutex g_mu_dec;  // one cct_decode_batch at a time; its host INFLATE phase runs outside g_mu so that
@@ -723,7 +725,9 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	// h_packed_offsets != NULL: archive layout -- files back to back in h_out (capacity out_stride bytes in
 	// total), h_packed_offsets[n+1]; needs the device DEFLATE path (or deflate off)
 	const bool packed = h_packed_offsets != nullptr;
+	const double t_call0 = now_ms();
 	std::unique_lock<std::mutex> lk(g_mu);
+	const double t_lock0 = now_ms();
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
@@ -764,7 +768,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	const bool one_pass = defl && g_ctx.device_deflate && (size_t)n * stride <= ((size_t)1 << 28);
 	if (!one_pass) {
 		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-		HIP_TRY(hipEventElapsedTime(&g_ctx.t_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
 	}
 	uint8_t hdr13[13];  // core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
 	hdr13[0] = (uint8_t)magic[0]; hdr13[1] = (uint8_t)magic[1]; hdr13[2] = (uint8_t)magic[2]; hdr13[3] = (uint8_t)magic[3];
@@ -782,7 +786,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		const size_t zstride = cct_file_bound(width, height, block_size);
 		// bounded workspaces: at most 2^28 payload bytes per pass (the corpus config is 3954 slices)
 		const int chunk = (int)std::max<size_t>(1, ((size_t)1 << 28) / stride);
-		g_ctx.t_deflate_ms = 0; g_ctx.t_d2h_ms = 0;
+		tl_deflate_ms = 0; tl_d2h_ms = 0;
 		for (int c0 = 0; c0 < n; c0 += chunk) {
 			const int nc = std::min(chunk, n - c0);
 			HIP_TRY(hipEventRecord(g_ctx.ev_z0, g_ctx.stream));
@@ -795,11 +799,11 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 			HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_z0, g_ctx.ev_z1));
 			if (one_pass) {
-				HIP_TRY(hipEventElapsedTime(&g_ctx.t_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
 				for (int i = 0; i < n; i++)
 					if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
 			}
-			g_ctx.t_deflate_ms += g_ctx.t_dev_deflate_ms;
+			tl_deflate_ms += g_ctx.t_dev_deflate_ms;
 			const double t_c0 = now_ms();
 			// pack the files back to back on the device, one copy into pinned memory, threaded scatter
 			std::vector<size_t> offs(nc + 1, 0);
@@ -839,13 +843,14 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 					for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
 					if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 					const float t_defl = g_ctx.t_dev_deflate_ms;
+					const double t_unlock = now_ms();
 					lk.unlock();
 					HIP_TRY(hipEventSynchronize(done));
 					const float t_tail = (float)(now_ms() - t_c0);
 					if (getenv("CCT_TRACE"))
-						fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h (lock released) %.2f ms (%zu bytes)\n", nc, t_defl, t_tail, exact);
-					lk.lock();
-					g_ctx.t_d2h_ms = t_tail;
+						fprintf(stderr, "[cct] encode n=%d: waited for the lock %.2f ms, held it %.2f ms (kernel %.2f, deflate %.2f), tail %.2f ms, t=%.2f\n", nc,
+						        t_lock0 - t_call0, t_unlock - t_lock0, tl_enc_kernel_ms, t_defl, now_ms() - t_unlock, t_lock0);
+					tl_d2h_ms = t_tail;  // (no lock: a float for cct_last_timings; re-locking would wait for the next batch)
 					return CCT_OK;
 				}
 				HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
@@ -868,7 +873,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 					});
 				}
 				for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
-				g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
+				tl_d2h_ms += (float)(now_ms() - t_c0);
 				if (getenv("CCT_TRACE"))
 					fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
 					        g_ctx.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, exact);
@@ -881,7 +886,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
 			parallel_for(nc, std::min(g_ctx.zlib_threads, 32),
 			             [&](int i) { memcpy(h_out + (size_t)(c0 + i) * out_stride, stg + offs[i], osz[i]); });
-			g_ctx.t_d2h_ms += (float)(now_ms() - t_c0);
+			tl_d2h_ms += (float)(now_ms() - t_c0);
 		}
 		if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 		return CCT_OK;
@@ -896,7 +901,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	}
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 	const double t_defl0 = now_ms();
-	g_ctx.t_d2h_ms = (float)(t_defl0 - t_copy0);
+	tl_d2h_ms = (float)(t_defl0 - t_copy0);
 
 	std::atomic<int> zerr(0);
 	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
@@ -913,7 +918,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			h_out_sizes[i] = 13 + psz[i];
 		}
 	});
-	g_ctx.t_deflate_ms = (float)(now_ms() - t_defl0);
+	tl_deflate_ms = (float)(now_ms() - t_defl0);
 	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
 	return CCT_OK;
@@ -1130,8 +1135,8 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		if (!images_on_device)
 			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipEventElapsedTime(&g_ctx.t_inflate_ms, g_ctx.ev_d0, g_ctx.ev_d1));
-		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, ev_k, ev_k1));
+		HIP_TRY(hipEventElapsedTime(&tl_inflate_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		HIP_TRY(hipEventElapsedTime(&tl_dec_kernel_ms, ev_k, ev_k1));
 		(void)t_inf0;
 	} else {
 	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421 -- host threads, no device lock held
@@ -1154,7 +1159,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	const float t_inflate = (float)(now_ms() - t_inf0);
 	{  // device phase on the decode stream (no device lock: the HIP runtime is thread-safe)
 		hipStream_t st = g_ctx.stream_dec;
-		g_ctx.t_inflate_ms = t_inflate;
+		tl_inflate_ms = t_inflate;
 		// one strided copy of the used part of every staged payload (a copy per slice costs more in launches
 		// than in bytes)
 		size_t used = 16;
@@ -1173,10 +1178,10 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		if (!images_on_device)
 			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipEventElapsedTime(&g_ctx.t_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		HIP_TRY(hipEventElapsedTime(&tl_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
 		if (getenv("CCT_TRACE"))
 			fprintf(stderr, "[cct] decode n=%d: inflate %.2f ms, h2d+kernel+sync %.2f ms (kernel %.2f), used %zu of stride %zu\n", n,
-			        t_inflate, now_ms() - t_h0, g_ctx.t_dec_kernel_ms, used, stride);
+			        t_inflate, now_ms() - t_h0, tl_dec_kernel_ms, used, stride);
 	}
 	}
 	int first = CCT_OK;
@@ -1199,9 +1204,10 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 
 int cct_last_timings(float *out6)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
-	out6[0] = g_ctx.t_enc_kernel_ms; out6[1] = g_ctx.t_d2h_ms; out6[2] = g_ctx.t_deflate_ms;
-	out6[3] = g_ctx.t_inflate_ms; out6[4] = g_ctx.t_dec_kernel_ms; out6[5] = g_ctx.t_h2d_ms;
+	// no lock: this only reads a few floats, and taking the device lock here would park the caller behind a
+	// whole batch that another thread is encoding
+	out6[0] = tl_enc_kernel_ms; out6[1] = tl_d2h_ms; out6[2] = tl_deflate_ms;
+	out6[3] = tl_inflate_ms; out6[4] = tl_dec_kernel_ms; out6[5] = tl_h2d_ms;
 	return CCT_OK;
 }
 

@@ -76,7 +76,7 @@ def cpu_baseline(batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slices", type=int, default=SLICES_PER_GPU, help="slices per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -184,9 +184,11 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
                      size_t images_cap_px, uint32_t *h_status /* CCT_E_* code per file */);
 
 /* ---- tuning / introspection (bench.py) --------------------------------------------- */
-/* Stage times of the most recent cct_encode_batch / cct_decode_batch, milliseconds:
- * [0] encode kernel (HIP events on the library stream), [1] payload D2H, [2] DEFLATE (host wall),
- * [3] INFLATE (host wall), [4] decode kernel (HIP events), [5] reserved. */
+/* Stage times of the CALLING THREAD's most recent cct_encode_batch / cct_decode_batch, milliseconds (kept per
+ * thread: an encode and a decode driven from two threads do not overwrite each other; takes no lock):
+ * [0] encode kernel (HIP events on the library stream), [1] packed files device -> host, [2] DEFLATE (HIP events
+ * on the device path, host wall on the libz path), [3] INFLATE (likewise), [4] decode kernel (HIP events),
+ * [5] reserved. */
 int cct_last_timings(float *out6);
 int cct_set_option(const char *key, int value);  /* "zlib_threads", "wg_threads", ... */
 int cct_get_option(const char *key, int *value);
