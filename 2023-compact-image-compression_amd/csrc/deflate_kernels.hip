@@ -458,12 +458,12 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 // through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
 __global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
 {
-	// one workgroup per slice: ordered lists of the ends AND starts of runs of >= 3 equal bytes.  Every lane scans
-	// a contiguous stretch of the slice twice (count, then write at the scanned offsets); a run is reported by the
-	// lane that sees its third byte (start) and the byte after it (end), which keeps both lists in position order.
-	// The k-th start belongs to the k-th end, which gives the run length without scanning.
+	// one workgroup per slice: ordered lists of the ends AND starts of runs of >= 3 equal bytes.  The slice is read
+	// in coalesced chunks of 8192 bytes (8 per lane); per chunk a workgroup prefix sum over the flag counts places
+	// the entries, so both lists come out in position order.  The k-th start belongs to the k-th end, which gives
+	// the run length without scanning.
 	// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
-	__shared__ uint32_t wsum_e[16], wsum_s[16];
+	__shared__ uint32_t wsum_e[2][16], wsum_s[2][16];
 	const int s = blockIdx.x;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
@@ -471,53 +471,52 @@ __global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
 	uint32_t *rs = re + (a.in_stride >> 2);
 	uint32_t *rl = re + (a.in_stride >> 1);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t per = (((L + 1023) / 1024) + 7) & ~7u;
-	const uint32_t x0 = min(L, (uint32_t)tid * per), x1 = min(L, x0 + per);
-	// equal bytes ending at x0 - 1, capped at 3
-	uint32_t run0 = 0;
-	if (x0 >= 1 && x0 < L) {
-		run0 = 1;
-		if (x0 >= 2 && in[x0 - 2] == in[x0 - 1]) { run0 = 2; if (x0 >= 3 && in[x0 - 3] == in[x0 - 1]) run0 = 3; }
-	}
-	uint32_t ie = 0, is = 0, nre = 0;
-	for (int pass = 0; pass < 2; pass++) {
-		uint32_t run = run0, ne = 0, ns = 0;
-		uint8_t prev = x0 >= 1 && x0 < L ? in[x0 - 1] : 0;
-		for (uint32_t xb = x0; xb < x1; xb += 8) {
-			uint64_t w = 0;
-			if (xb + 8 <= L) __builtin_memcpy(&w, in + xb, 8);
-			else for (uint32_t k = 0; xb + k < L; k++) w |= (uint64_t)in[xb + k] << (8 * k);
+	auto load8 = [&](int64_t x) -> uint64_t {  // bytes in[x .. x+7], zero outside [0, L)
+		uint64_t w = 0;
+		if (x >= 0 && x + 8 <= (int64_t)L) __builtin_memcpy(&w, in + x, 8);
+		else for (int k = 0; k < 8; k++) { const int64_t y = x + k; if (y >= 0 && y < (int64_t)L) w |= (uint64_t)in[y] << (8 * k); }
+		return w;
+	};
+	uint32_t base_e = 0, base_s = 0;
+	int par = 0;
+	for (uint32_t c0 = 0; c0 < L; c0 += 8192, par ^= 1) {
+		const uint32_t x0 = c0 + (uint32_t)tid * 8;
+		uint32_t me = 0, ms = 0;
+		if (x0 < L) {
+			const uint64_t wp = load8((int64_t)x0 - 8), wc = load8(x0), wn = load8((int64_t)x0 + 8);
+			auto bt = [&](int i) -> uint32_t {  // in[x0 + i], i in [-3, 9]
+				return i < 0 ? (uint32_t)(wp >> (8 * (i + 8))) & 0xFFu : i < 8 ? (uint32_t)(wc >> (8 * i)) & 0xFFu : (uint32_t)(wn >> (8 * (i - 8))) & 0xFFu;
+			};
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
-				const uint32_t x = xb + k;
-				if (x < x1) {
-					const uint8_t c = (uint8_t)(w >> (8 * k));
-					if (x >= 1 && c == prev) {
-						if (run == 2) { if (pass) rs[is + ns] = x - 2; ns++; }
-						if (run < 3) run++;
-					} else {
-						if (run == 3) { if (pass) re[ie + ne] = x; ne++; }
-						run = 1;
-					}
-					prev = c;
-				}
+				const uint32_t x = x0 + k;
+				const bool e = x >= 3 && x < L && bt(k - 1) == bt(k - 2) && bt(k - 2) == bt(k - 3) && bt(k) != bt(k - 1);
+				const bool st = x + 2 < L && bt(k + 1) == bt(k) && bt(k + 2) == bt(k) && (x == 0 || bt(k - 1) != bt(k));
+				me |= (uint32_t)e << k; ms |= (uint32_t)st << k;
 			}
 		}
-		if (pass == 0) {  // exclusive scans of both counters over the workgroup
-			uint32_t inc_e = ne, inc_s = ns;
+		const uint32_t ne = (uint32_t)__popc(me), ns = (uint32_t)__popc(ms);
+		uint32_t inc_e = ne, inc_s = ns;
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t oe = __shfl_up(inc_e, d, 64), os = __shfl_up(inc_s, d, 64);
-				if (lane >= d) { inc_e += oe; inc_s += os; }
-			}
-			if (lane == 63) { wsum_e[wave] = inc_e; wsum_s[wave] = inc_s; }
-			__syncthreads();
-			ie = inc_e - ne; is = inc_s - ns;
-			uint32_t tot = 0;
-			for (int w2 = 0; w2 < 16; w2++) { if (w2 < wave) { ie += wsum_e[w2]; is += wsum_s[w2]; } tot += wsum_e[w2]; }
-			nre = tot;
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t oe = __shfl_up(inc_e, d, 64), os = __shfl_up(inc_s, d, 64);
+			if (lane >= d) { inc_e += oe; inc_s += os; }
+		}
+		if (lane == 63) { wsum_e[par][wave] = inc_e; wsum_s[par][wave] = inc_s; }
+		__syncthreads();  // (double-buffered sums: one barrier per chunk)
+		uint32_t ie = base_e + inc_e - ne, is = base_s + inc_s - ns;
+		for (int w2 = 0; w2 < 16; w2++) {
+			const uint32_t te = wsum_e[par][w2], ts = wsum_s[par][w2];
+			if (w2 < wave) { ie += te; is += ts; }
+			base_e += te; base_s += ts;
+		}
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			if ((me >> k) & 1u) re[ie++] = x0 + k;
+			if ((ms >> k) & 1u) rs[is++] = x0 + k;
 		}
 	}
+	const uint32_t nre = base_e;
 	if (tid == 0) a.run_end_count[s] = nre;
 	__threadfence();
 	__syncthreads();
