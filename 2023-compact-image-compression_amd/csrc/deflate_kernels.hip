@@ -1242,6 +1242,14 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 		t_dcode[threadIdx.x] = dyn ? bt->dcode[threadIdx.x] : c_static_dcode[threadIdx.x];
 		t_dlen[threadIdx.x] = dyn ? bt->dlen[threadIdx.x] : (uint8_t)5;
 	}
+	// the symbol -> code tables of trees.c, staged in LDS: a __constant__ lookup with a per-lane index is a global
+	// load, and every iteration with a match in it would wait for four of them in a row
+	__shared__ uint8_t t_length_code[256], t_dist_code[512], t_extra_l[32], t_extra_d[32];
+	__shared__ uint16_t t_base_length[32], t_base_dist[32];
+	for (int i = threadIdx.x; i < 512; i += blockDim.x) t_dist_code[i] = c_dist_code[i];
+	t_length_code[threadIdx.x] = c_length_code[threadIdx.x];  // blockDim.x == 256
+	if (threadIdx.x < 29) { t_extra_l[threadIdx.x] = c_extra_lbits[threadIdx.x]; t_base_length[threadIdx.x] = c_base_length[threadIdx.x]; }
+	if (threadIdx.x < 30) { t_extra_d[threadIdx.x] = c_extra_dbits[threadIdx.x]; t_base_dist[threadIdx.x] = c_base_dist[threadIdx.x]; }
 	if (threadIdx.x == 0) s_run = bit;
 	for (int i = threadIdx.x; i < 400; i += blockDim.x) wbuf[i] = 0;
 	__syncthreads();
@@ -1257,18 +1265,18 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 				bits = t_lcode[lc];
 				nb = t_llen[lc];
 			} else {  // compress_block, trees.c:1070-1110
-				int code = c_length_code[lc];
+				int code = t_length_code[lc];
 				const int lsym = code + 256 + 1;
 				bits = t_lcode[lsym];
 				nb = t_llen[lsym];
-				int extra = c_extra_lbits[code];
-				if (extra) { bits |= (uint64_t)(lc - c_base_length[code]) << nb; nb += extra; }
+				int extra = t_extra_l[code];
+				if (extra) { bits |= (uint64_t)(lc - t_base_length[code]) << nb; nb += extra; }
 				dist--;
-				code = d_code(dist);
+				code = dist < 256 ? t_dist_code[dist] : t_dist_code[256 + (dist >> 7)];
 				bits |= (uint64_t)t_dcode[code] << nb;
 				nb += t_dlen[code];
-				extra = c_extra_dbits[code];
-				if (extra) { bits |= (uint64_t)(dist - c_base_dist[code]) << nb; nb += extra; }
+				extra = t_extra_d[code];
+				if (extra) { bits |= (uint64_t)(dist - t_base_dist[code]) << nb; nb += extra; }
 			}
 		} else if (i == bm.nsym) {
 			bits = t_lcode[END_BLOCK];
