@@ -148,9 +148,12 @@ __device__ __forceinline__ Parse parse_step(const uint4 &w, uint32_t nxt, int nv
 	return p;
 }
 
-template <int BS>
+// TAB_LDS: the per-block role bytes and the slot table (5 bytes per block) live in LDS instead of the HBM
+// workspace: pass B looks both up for every pixel (fits up to 24 K blocks, e.g. 512 x 512 at block size 16)
+template <int BS, bool TAB_LDS>
 __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 {
+	extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 	__shared__ uint32_t scratch[64];
 	__shared__ uint32_t l_jord[DEC_JLIST_CAP];
 	__shared__ uint8_t l_jval[DEC_JLIST_CAP];
@@ -165,14 +168,22 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	const uint32_t Lr = min((uint32_t)a.stride, L) > 0 ? min((uint32_t)a.stride, L) - 1u : 0u;
 	const int32_t *lut = a.lut;
 	uint16_t *out = a.images + (size_t)s * N;
-	uint8_t *role = a.ws_role + (size_t)s * NB;
-	uint32_t *slot_tab = a.ws_slot + (size_t)s * NB;
+	typedef __attribute__((address_space(3))) uint8_t lds_u8;
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	lds_u32 *l_slot = (lds_u32 *)dyn_lds;                       // NB words
+	lds_u8 *l_role = (lds_u8 *)(dyn_lds + (size_t)NB * 4);      // NB bytes
+	uint8_t *g_role = a.ws_role + (size_t)s * NB;
+	uint32_t *g_slot = a.ws_slot + (size_t)s * NB;
+	auto role_rd = [&](uint32_t b) -> uint32_t { return TAB_LDS ? (uint32_t)l_role[b] : (uint32_t)g_role[b]; };
+	auto role_wr = [&](uint32_t b, uint32_t v) { if (TAB_LDS) l_role[b] = (uint8_t)v; else g_role[b] = (uint8_t)v; };
+	auto slot_rd = [&](uint32_t i) -> uint32_t { return TAB_LDS ? l_slot[i] : g_slot[i]; };
+	auto slot_wr = [&](uint32_t i, uint32_t v) { if (TAB_LDS) l_slot[i] = v; else g_slot[i] = v; };
 	const size_t jcap = (size_t)NB / 2 + 1;
 	uint32_t *g_jord = a.ws_jord + (size_t)s * jcap;
 	uint8_t *g_jval = a.ws_jval + (size_t)s * jcap;
 
 	if (tid == 0) s_status = 0;
-	for (int b = tid; b < NB; b += T) role[b] = 0;
+	for (int b = tid; b < NB; b += T) role_wr((uint32_t)b, 0);
 	__syncthreads();
 
 	auto load_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt, int &nvalid) {
@@ -240,8 +251,8 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 			while (win & 1ull) { F++; win >>= 1; }
 			const uint32_t Lb = F, pb = F + j;
 			if (j == 0 || pb >= (uint32_t)NB || ((win >> j) & 1ull)) { bad = true; break; }
-			role[Lb] = (uint8_t)j;
-			role[pb] = ROLE_PARTNER;
+			role_wr(Lb, j);
+			role_wr(pb, ROLE_PARTNER);
 			win |= 1ull << j;
 			F = Lb + 1;
 			win >>= 1;
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		for (int base = 0; base < NB; base += T) {
 			const int b = base + tid;
 			uint32_t r = ROLE_PARTNER, cnt = 0;
-			if (b < NB) { r = role[b]; cnt = (r == ROLE_PARTNER) ? 0u : (r ? 2u : 1u); }
+			if (b < NB) { r = role_rd((uint32_t)b); cnt = (r == ROLE_PARTNER) ? 0u : (r ? 2u : 1u); }
 			const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
 			const uint32_t inc = wave_incl_scan_u32(cnt);
 			if (lane == 63) scratch[wave] = inc;
@@ -266,8 +277,8 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 			for (int x = 0; x < nw; x++) { const uint32_t v = scratch[x]; if (x < wave) bs_ += v; tot += v; }
 			__syncthreads();
 			const uint32_t sl = slot_c + bs_ + inc - cnt;
-			if (cnt >= 1 && sl < (uint32_t)NB) slot_tab[sl] = (uint32_t)b | (cnt == 2 ? (1u << 30) : 0u);
-			if (cnt == 2 && sl + 1 < (uint32_t)NB) slot_tab[sl + 1] = (uint32_t)b | (2u << 30);
+			if (cnt >= 1 && sl < (uint32_t)NB) slot_wr(sl, (uint32_t)b | (cnt == 2 ? (1u << 30) : 0u));
+			if (cnt == 2 && sl + 1 < (uint32_t)NB) slot_wr(sl + 1, (uint32_t)b | (2u << 30));
 			slot_c += tot;
 		}
 		if (slot_c != (uint32_t)NB && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
@@ -310,13 +321,13 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 					after_jump = false;
 					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
 					const uint32_t sl = ord / BS, t = ord % BS;
-					const uint32_t ent = slot_tab[sl];
+					const uint32_t ent = slot_rd(sl);
 					const uint32_t b = ent & 0x3FFFFFFFu, kind = ent >> 30;
 					uint32_t pos;
 					if (kind == 0) pos = b * BS + t;
 					else {
 						const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
-						const uint32_t blk = (mm & 1u) ? b + role[b] : b;
+						const uint32_t blk = (mm & 1u) ? b + role_rd(b) : b;
 						pos = blk * BS + (mm >> 1);
 					}
 					out[lut ? lut[pos] : (int)pos] = (uint16_t)val;
@@ -335,16 +346,23 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 
 hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s)
 {
+	const size_t tab_bytes = (size_t)a.NB * 5 + 16;
+	const bool tab_lds = tab_bytes <= 120 * 1024;
 	void (*k)(DecArgs) = nullptr;
 	switch (block_size) {
-	case 4: k = decode_kernel<4>; break;
-	case 8: k = decode_kernel<8>; break;
-	case 16: k = decode_kernel<16>; break;
-	case 32: k = decode_kernel<32>; break;
-	case 64: k = decode_kernel<64>; break;
+	case 4: k = tab_lds ? decode_kernel<4, true> : decode_kernel<4, false>; break;
+	case 8: k = tab_lds ? decode_kernel<8, true> : decode_kernel<8, false>; break;
+	case 16: k = tab_lds ? decode_kernel<16, true> : decode_kernel<16, false>; break;
+	case 32: k = tab_lds ? decode_kernel<32, true> : decode_kernel<32, false>; break;
+	case 64: k = tab_lds ? decode_kernel<64, true> : decode_kernel<64, false>; break;
 	default: return hipErrorInvalidValue;
 	}
-	hipLaunchKernelGGL(k, dim3(n), dim3(threads), 0, s, a);
+	const size_t lds = tab_lds ? tab_bytes : 0;
+	if (lds) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(k, dim3(n), dim3(threads), lds, s, a);
 	return hipGetLastError();
 }
 
