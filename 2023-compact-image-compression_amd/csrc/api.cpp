@@ -501,7 +501,17 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	DecArgs a{};
 	a.payload = d_payload; a.stride = stride; a.sizes = d_sizes;
 	a.lut = nullptr;
-	if (fractal) { int rc = get_lut(width, height, &a.lut); if (rc) return rc; }
+	a.n_tiles = 0; a.n_orient = 0; a.width = width;
+	if (fractal) {
+		const ShapeTables *tb;
+		int rc0 = get_tables(width, height, &tb);
+		if (rc0) return rc0;
+		a.lut = tb->d_lut;
+		if (tb->tiled && g_ctx.use_tiles) {
+			a.tile_org = tb->d_org; a.tile_orient = tb->d_orient; a.patterns = tb->d_pat;
+			a.n_tiles = tb->n_tiles; a.n_orient = tb->n_orient;
+		}
+	}
 	a.N = N; a.NB = NB; a.images = d_images; a.status = d_status;
 	const size_t per = (size_t)n * NB, jper = (size_t)n * ((size_t)NB / 2 + 1);
 	int rc;

@@ -63,6 +63,9 @@ struct DecArgs {
 	uint32_t *ws_slot;        // n * NB: stream slot -> leader block | kind << 30
 	uint32_t *ws_jord;        // n * (NB/2+1) spill: jump ordinals
 	uint8_t *ws_jval;         // n * (NB/2+1) spill: jump distances
+	// traversal made of aligned 64x64 tiles (same tables as encode_tiles_kernel): position -> raster offset from LDS
+	const uint32_t *tile_org; const uint8_t *tile_orient; const uint16_t *patterns;
+	int n_tiles, n_orient, width;   // n_tiles == 0: use lut
 };
 
 hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s);

@@ -150,7 +150,9 @@ __device__ __forceinline__ Parse parse_step(const uint4 &w, uint32_t nxt, int nv
 
 // TAB_LDS: the per-block role bytes and the slot table (5 bytes per block) live in LDS instead of the HBM
 // workspace: pass B looks both up for every pixel (fits up to 24 K blocks, e.g. 512 x 512 at block size 16)
-template <int BS, bool TAB_LDS>
+// TILED: the traversal is made of aligned 64x64 tiles; the position -> raster map comes from the pattern tables of
+// encode_tiles_kernel staged in LDS (<= 32 KB) instead of one 4-byte HBM/L2 load per pixel.
+template <int BS, bool TAB_LDS, bool TILED = false>
 __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -178,6 +180,24 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	auto role_wr = [&](uint32_t b, uint32_t v) { if (TAB_LDS) l_role[b] = (uint8_t)v; else g_role[b] = (uint8_t)v; };
 	auto slot_rd = [&](uint32_t i) -> uint32_t { return TAB_LDS ? l_slot[i] : g_slot[i]; };
 	auto slot_wr = [&](uint32_t i, uint32_t v) { if (TAB_LDS) l_slot[i] = v; else g_slot[i] = v; };
+	typedef __attribute__((address_space(3))) uint16_t lds_u16;
+	lds_u16 *l_pat = (lds_u16 *)(dyn_lds + (((size_t)NB * 5 + 15) & ~(size_t)15));   // n_orient * 4096
+	lds_u32 *l_torg = (lds_u32 *)(l_pat + (TILED ? (size_t)a.n_orient * 4096 : 0)); // n_tiles
+	lds_u8 *l_tori = (lds_u8 *)(l_torg + (TILED ? a.n_tiles : 0));                   // n_tiles
+	if (TILED) {
+		for (int i = tid; i < a.n_orient * 4096; i += T) l_pat[i] = a.patterns[i];
+		for (int i = tid; i < a.n_tiles; i += T) { l_torg[i] = a.tile_org[i]; l_tori[i] = a.tile_orient[i]; }
+	}
+	// raster offset of traversal position pos
+	auto raster_of = [&](uint32_t pos) -> uint32_t {
+		if (TILED) {
+			const uint32_t tile = pos >> 12;
+			const uint32_t pv = l_pat[(uint32_t)l_tori[tile] * 4096u + (pos & 4095u)];  // dy*128 + ((dx>>3 ^ dy&7) << 4) + (dx&7)*2
+			const uint32_t dy = pv >> 7, dx = ((((pv >> 4) & 7u) ^ (dy & 7u)) << 3) | ((pv & 15u) >> 1);
+			return l_torg[tile] + dy * (uint32_t)a.width + dx;
+		}
+		return lut ? (uint32_t)lut[pos] : pos;
+	};
 	const size_t jcap = (size_t)NB / 2 + 1;
 	uint32_t *g_jord = a.ws_jord + (size_t)s * jcap;
 	uint8_t *g_jval = a.ws_jval + (size_t)s * jcap;
@@ -330,7 +350,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 						const uint32_t blk = (mm & 1u) ? b + role_rd(b) : b;
 						pos = blk * BS + (mm >> 1);
 					}
-					out[lut ? lut[pos] : (int)pos] = (uint16_t)val;
+					out[raster_of(pos)] = (uint16_t)val;
 					ord++;
 				}
 			}
@@ -346,18 +366,20 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 
 hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s)
 {
-	const size_t tab_bytes = (size_t)a.NB * 5 + 16;
-	const bool tab_lds = tab_bytes <= 120 * 1024;
+	const size_t tab_bytes = (((size_t)a.NB * 5 + 15) & ~(size_t)15) + 16;
+	const bool tab_lds = tab_bytes <= 100 * 1024;
+	const size_t tile_bytes = (size_t)a.n_orient * 8192 + (size_t)a.n_tiles * 5 + 16;
+	const bool tiled = tab_lds && block_size == 16 && a.lut && a.n_tiles > 0 && tab_bytes + tile_bytes <= 144 * 1024;
 	void (*k)(DecArgs) = nullptr;
 	switch (block_size) {
 	case 4: k = tab_lds ? decode_kernel<4, true> : decode_kernel<4, false>; break;
 	case 8: k = tab_lds ? decode_kernel<8, true> : decode_kernel<8, false>; break;
-	case 16: k = tab_lds ? decode_kernel<16, true> : decode_kernel<16, false>; break;
+	case 16: k = tiled ? decode_kernel<16, true, true> : tab_lds ? decode_kernel<16, true> : decode_kernel<16, false>; break;
 	case 32: k = tab_lds ? decode_kernel<32, true> : decode_kernel<32, false>; break;
 	case 64: k = tab_lds ? decode_kernel<64, true> : decode_kernel<64, false>; break;
 	default: return hipErrorInvalidValue;
 	}
-	const size_t lds = tab_lds ? tab_bytes : 0;
+	const size_t lds = tab_lds ? tab_bytes + (tiled ? tile_bytes : 0) : 0;
 	if (lds) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
