@@ -290,6 +290,26 @@ def test_full_batch_properties(hip):
 
 
 @pytest.mark.parametrize("n_px", [128, 256, 512, 1024])
+def test_decode_tile_tables_equal_traversal_table(hip, n_px):
+    """decode_kernel maps positions to raster offsets through the LDS pattern tables when the traversal is made of
+    64x64 tiles, through the HBM traversal table otherwise: both must rebuild the same rasters (= the input)."""
+    from cct_hip import _ffi
+    cfg = hip.default_config()
+    L = _ffi.lib()
+    imgs = np.stack([gi.ct_phantom(90 + i, n_px) for i in range(3)])
+    files = hip.encode_batch(imgs, cfg)
+    outs = []
+    for tile in (1, 0):
+        _ffi.check(L.cct_set_option(b"tile_path", tile))
+        try:
+            outs.append(hip.decode_batch(files, cfg))
+        finally:
+            _ffi.check(L.cct_set_option(b"tile_path", 1))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(np.asarray(outs[0]).reshape(imgs.shape), imgs)
+
+
+@pytest.mark.parametrize("n_px", [128, 256, 512, 1024])
 def test_tile_path_equals_generic_path(hip, n_px):
     """The tile-staged fast kernel and the generic LUT-gather kernel must agree byte for byte
     (payload, sizes, statistics, block roles) -- and with the oracle."""
