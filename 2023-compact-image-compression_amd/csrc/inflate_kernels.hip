@@ -29,6 +29,7 @@ namespace cct {
 namespace {
 
 constexpr int NT = 256;                       // lanes per stream
+constexpr int NWV = NT / 64;                  // waves per stream
 constexpr int INF_RING = 65536, INF_RMASK = INF_RING - 1, INF_FLUSH = 4096;
 constexpr int INF_IN = 16384, INF_CHUNK = 4096;
 constexpr int LL_BITS = 11, D_BITS = 10;
@@ -64,7 +65,7 @@ struct InfShared {
 	uint8_t lext[29], dext[30];
 	// round state
 	uint32_t land[NT];                          // landing position of every lane, bits from the round's origin
-	uint32_t wsum_b[4], wsum_m[4], wred[8];
+	uint32_t wsum_b[NWV], wsum_m[NWV], wred[2 * NWV];
 	uint32_t rres[4];                           // result of the round: bytes, copies, landing position, flags of its last lane
 	int ok;
 };
@@ -311,9 +312,12 @@ __device__ __forceinline__ int first_lane_with(InfShared &S, bool pred, int slot
 {
 	const uint64_t bal = __ballot(pred);
 	const int wave = threadIdx.x >> 6;
-	if ((threadIdx.x & 63) == 0) S.wred[slot * 4 + wave] = bal ? (uint32_t)(wave * 64 + __ffsll((long long)bal) - 1) : (uint32_t)NT;
+	if ((threadIdx.x & 63) == 0) S.wred[slot * NWV + wave] = bal ? (uint32_t)(wave * 64 + __ffsll((long long)bal) - 1) : (uint32_t)NT;
 	__syncthreads();
-	return (int)min(min(S.wred[slot * 4 + 0], S.wred[slot * 4 + 1]), min(S.wred[slot * 4 + 2], S.wred[slot * 4 + 3]));
+	uint32_t r = (uint32_t)NT;
+#pragma unroll
+	for (int w = 0; w < NWV; w++) r = min(r, S.wred[slot * NWV + w]);
+	return (int)r;
 }
 
 __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
@@ -361,8 +365,9 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			__syncthreads();
 			if (lane == 0) { S.wsum_b[wave] = sa; S.wsum_m[wave] = sb; }
 			__syncthreads();
-			sa = S.wsum_b[0] + S.wsum_b[1] + S.wsum_b[2] + S.wsum_b[3];
-			sb = S.wsum_m[0] + S.wsum_m[1] + S.wsum_m[2] + S.wsum_m[3];
+			sa = 0; sb = 0;
+#pragma unroll
+			for (int w = 0; w < NWV; w++) { sa += S.wsum_b[w]; sb += S.wsum_m[w]; }
 			adB = (uint32_t)(((uint64_t)adB + (uint64_t)n * adA + sb) % 65521u);
 			adA = (adA + sa) % 65521u;
 			flushed += n;
