@@ -350,8 +350,7 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			const uint32_t n = min((uint32_t)INF_FLUSH, upto - flushed);
 			if ((size_t)flushed + ((n + 15) & ~15u) > a.out_stride) { err |= CCT_ST_STREAM; flushed += n; continue; }  // longer than any valid payload
 			uint32_t sa = 0, sb = 0;  // A += sum d ; B += n * A_old + sum (n - i) d_i
-			const uint32_t t = (uint32_t)tid * 16;  // flushed is a multiple of INF_FLUSH here
-			if (t < n) {
+			for (uint32_t t = (uint32_t)tid * 16; t < n; t += NT * 16) {  // flushed is a multiple of INF_FLUSH here
 				const uint4 v = *reinterpret_cast<const uint4 *>(S.ring + ((flushed + t) & INF_RMASK));
 				const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
