@@ -112,6 +112,8 @@ def main():
 
     if os.environ.get("CCT_DEFLATE_WAYS"):
         _ffi.check(L.cct_set_option(b"deflate_ways", int(os.environ["CCT_DEFLATE_WAYS"])))
+    if os.environ.get("CCT_WG_THREADS"):
+        _ffi.check(L.cct_set_option(b"wg_threads", int(os.environ["CCT_WG_THREADS"])))
     if os.environ.get("CCT_DEFLATE_GRAPH"):
         _ffi.check(L.cct_set_option(b"deflate_graph", int(os.environ["CCT_DEFLATE_GRAPH"])))
     if os.environ.get("CCT_DEVICE_INFLATE"):
