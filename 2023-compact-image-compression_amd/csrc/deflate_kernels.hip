@@ -661,8 +661,7 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 			const uint32_t n2 = __shfl(nxt, j), c2 = __shfl(cnt, j);
 			if (inside) { nxt = n2; cnt += c2; }
 		}
-		a.exit_pos[base + p] = nxt;
-		a.exit_cnt[base + p] = cnt;
+		a.exit_pos[base + p] = (nxt - blk_end) | (cnt << 16);  // both < 1024: one word per position (entry -> exit offset past the block, symbols)
 	}
 }
 
@@ -683,14 +682,14 @@ __global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 	const uint32_t L = a.in_sizes[s];
 	const size_t base = (size_t)s * a.in_stride;
 	const size_t bbase = (size_t)s * (a.in_stride / 64);
-	const uint32_t *exit_pos = a.exit_pos + base, *exit_cnt = a.exit_cnt + base;
+	const uint32_t *exit_rec = a.exit_pos + base;  // (offset of the exit past the entry's block) | symbols << 16
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t seg = (((L + 255) / 256) + 63) & ~63u;
 	const uint32_t seg_end = min(L, (uint32_t)(tid + 1) * seg);
 	uint32_t start = min(L, (uint32_t)tid * seg), land = start, cnt = 0;
 	auto hop_through = [&]() {
 		uint32_t cur = start, c = 0;
-		while (cur < seg_end) { c += exit_cnt[cur]; cur = exit_pos[cur]; }
+		while (cur < seg_end) { const uint32_t e = exit_rec[cur]; c += e >> 16; cur = (cur & ~63u) + 64u + (e & 0xFFFFu); }
 		land = cur; cnt = c;
 	};
 	hop_through();
@@ -716,8 +715,9 @@ __global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 		const uint32_t b = cur >> 6;
 		a.blk_entry[bbase + b] = cur;
 		a.blk_symbase[bbase + b] = syms;
-		syms += exit_cnt[cur];
-		cur = exit_pos[cur];
+		const uint32_t e = exit_rec[cur];
+		syms += e >> 16;
+		cur = (cur & ~63u) + 64u + (e & 0xFFFFu);
 	}
 }
 
