@@ -4,19 +4,25 @@
 // not vendored there; the algorithm is restated here in data-parallel form (CPU model of the same
 // restatement, pinned against libz: oracle/deflate_model.c).
 //
-//   hash      every payload position gets its 15-bit rolling hash of 3 bytes (deflate.c UPDATE_HASH)
-//   sort      stable segmented radix sort of (hash, position) per slice: a bucket in position
-//             order IS zlib's hash chain (head/prev), walked backwards
-//   match     one lane per position: what longest_match() returns over the first 4096 / 1024
-//             chain entries (max_chain, and max_chain>>2 once prev_length >= good_match), with the
-//             NIL / MAX_DIST / lookahead rules of deflate.c
+//   sort      stable two-pass LSD radix sort of (hash, position) per slice, the 15-bit rolling hash of 3 bytes
+//             (deflate.c UPDATE_HASH) computed on the fly: a bucket in position order IS zlib's hash chain
+//             (head/prev), walked backwards
+//   runs      ordered list of the runs of >= 3 equal bytes and, per position, the equal bytes ahead
+//   match     what longest_match() returns over the first 4096 / 1024 chain entries (max_chain, and
+//             max_chain>>2 once prev_length >= good_match), with the NIL / MAX_DIST / lookahead rules of
+//             deflate.c: one lane per position for short chains, one wave per position for long ones, and
+//             the run list instead of the chain for strings that start a run (their bucket holds every
+//             position of every run of that byte)
 //   parse     deflate_slow's lazy evaluation as a walk over "decision positions": per position the
 //             deferral chain is resolved locally, 64-position blocks are summarised by pointer
-//             doubling (entry -> exit, symbol count), one lane per slice hops block to block
+//             doubling (entry -> exit, symbol count), the block-to-block hop chain is walked
+//             speculatively by 256 lanes per slice
 //   symbols   visited positions emit literals / (length, distance) pairs in stream order
 //   trees     per 16383-symbol block: histograms, then build_tree / gen_bitlen / gen_codes /
-//             scan_tree / build_bl_tree exactly as trees.c, stored / static / dynamic choice
+//             scan_tree / build_bl_tree exactly as trees.c (the heap is replayed: ties are decided by heap
+//             position), stored / static / dynamic choice
 //   emit      code bits of every symbol at its prefix-summed bit offset; zlib header, Adler-32
+// The launches of one pass are captured into a HIP graph by the caller (api.cpp).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>
