@@ -306,6 +306,42 @@ __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, u
 	land = lane_pos(lb, org_dword);
 }
 
+// The code-length sequence of a dynamic block header (<= 316 entries, run-length coded with the 19-symbol code)
+// is the same kind of chain as the block body, so wave 0 decodes it the same way: 64 segments of CL_SEG bits,
+// restarts until no start moves, prefix sum of the entry counts, second walk that writes S.lens.  A "repeat the
+// previous length" symbol (16) writes markers that a scan resolves afterwards.
+constexpr int CL_SEG = 64;
+constexpr uint32_t CL_BAD = 1, CL_OVER = 2;
+constexpr uint8_t CL_PREV = 0xFF;  // marker: same as the entry before (lengths are <= 15)
+
+template <bool EMIT>
+__device__ __forceinline__ void cl_walk(InfShared &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t limit,
+                                        uint32_t idx_base, uint32_t &land, uint32_t &cnt, uint32_t &flags)
+{
+	LaneBits lb;
+	lane_init(S, lb, org_dword, start);
+	cnt = 0; flags = 0;
+	while (lane_pos(lb, org_dword) < end) {
+		if (EMIT && cnt == limit) break;  // the sequence is complete: the block body starts here
+		lane_refill(S, lb);
+		const uint32_t lo = (uint32_t)lb.buf;
+		const uint32_t ce = S.cl_tab[lo & ((1u << CL_BITS) - 1u)];
+		if (ce == 0) { flags = CL_BAD; break; }
+		const uint32_t sym = ce >> 3, cb = ce & 7u;
+		const uint32_t xb = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+		const uint32_t xv = (lo >> cb) & ((1u << xb) - 1u);
+		const uint32_t rep = sym < 16 ? 1u : sym == 18 ? 11u + xv : 3u + xv;
+		if (EMIT) {
+			if (rep > limit - cnt) { flags = CL_OVER; break; }  // repeat beyond the last entry
+			const uint8_t v = sym < 16 ? (uint8_t)sym : sym == 16 ? CL_PREV : (uint8_t)0;
+			for (uint32_t t = 0; t < rep; t++) S.lens[idx_base + cnt + t] = v;
+		}
+		lb.buf >>= (cb + xb); lb.cnt -= (int)(cb + xb);
+		cnt += rep;
+	}
+	land = lane_pos(lb, org_dword);
+}
+
 // smallest lane index (0..255) whose predicate is set, NT if none; all lanes call it (one barrier inside, and
 // what was written to LDS before the call is visible to everybody after it)
 __device__ __forceinline__ int first_lane_with(InfShared &S, bool pred, int slot)
@@ -430,54 +466,79 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			build_cl(S);
 			if (!S.ok) { err = CCT_ST_ZLIB; break; }
 			// the code lengths of both alphabets, run-length coded; S.lens is reused after cl is built
-			int idx = 0;
-			uint8_t prev_len = 0;
 			{
-				// This loop is one dependent chain of ~316 table lookups.  Every lane holds the same reader state, but
-				// in vector registers; readfirstlane moves it to the scalar unit, whose dependent operations cost a
-				// cycle or two instead of a vector-pipeline pass each.
-				while (br.bytepos + 1024 > br.staged_end) stage_chunk(S, br);  // the header is < 700 bytes
-				const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
-				uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(br.buf >> 32)) << 32) |
-				              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)br.buf);
-				int sc = __builtin_amdgcn_readfirstlane(br.cnt);
-				uint32_t sw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(br.bytepos >> 2));  // next dword
-				const uint32_t sw0 = sw;
-				const int total = nlen + ndist;
-				uint32_t lerr = 0;
-				if (wave == 0) {  // one wave walks the chain; the others wait at the barrier and leave their issue slots free
-					while (idx < total) {
-						if (sc < 16) {
-							const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)in32[sw & (INF_IN / 4 - 1)]);
-							sb |= (uint64_t)w << sc; sc += 32; sw++;
+				while (br.bytepos + 2048 > br.staged_end) stage_chunk(S, br);  // the sequence is < 700 bytes
+				const uint32_t total = (uint32_t)(nlen + ndist);
+				const uint64_t b0 = br.bytepos * 8u - (uint64_t)br.cnt;
+				if (wave == 0) {  // the other waves wait at the barrier below
+					uint32_t idx = 0, lerr = 0;
+					uint64_t bp = b0;
+					while (idx < total && !lerr) {
+						const uint32_t org_dword = (uint32_t)(bp >> 5), org_bit = (uint32_t)bp & 31u;
+						const uint32_t nominal = org_bit + (uint32_t)lane * CL_SEG, seg_end = nominal + CL_SEG;
+						uint32_t start = nominal, land, cnt, fl;
+						cl_walk<false>(S, org_dword, start, seg_end, 0, 0, land, cnt, fl);
+						int first;
+						for (;;) {  // restart from where the previous lane really landed until nothing moves
+							const uint32_t pl = __shfl_up(land, 1, 64);
+							const uint64_t flagged = __ballot(fl != 0);
+							first = flagged ? __ffsll((long long)flagged) - 1 : 64;
+							const bool moved = lane > 0 && lane <= first && pl != start;
+							if (!__ballot(moved)) break;
+							if (moved) { start = pl; cl_walk<false>(S, org_dword, start, seg_end, 0, 0, land, cnt, fl); }
 						}
-						const uint32_t lo = (uint32_t)sb;
-						const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.cl_tab[lo & ((1u << CL_BITS) - 1u)]);
-						if (ce == 0) { lerr = 1; break; }
-						const int sym = (int)(ce >> 3);
-						const uint32_t cbits = ce & 7u, xbits = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
-						const uint32_t xval = (lo >> cbits) & ((1u << xbits) - 1u);
-						sb >>= (cbits + xbits); sc -= (int)(cbits + xbits);
-						if (sym < 16) { if (lane == 0) S.lens[idx] = (uint8_t)sym; prev_len = (uint8_t)sym; idx++; }
-						else {
-							int rep; uint8_t v = 0;
-							if (sym == 16) { if (idx == 0) { lerr = 1; break; } v = prev_len; rep = 3 + (int)xval; }
-							else if (sym == 17) rep = 3 + (int)xval;
-							else rep = 11 + (int)xval;
-							if (idx + rep > total) { lerr = 1; break; }
-							for (int t = lane; t < rep; t += 64) S.lens[idx + t] = v;
-							idx += rep;
-							if (sym != 16) prev_len = 0;
+						uint32_t inc = cnt;  // entries up to and including this lane
+#pragma unroll
+						for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+						const uint32_t remaining = total - idx, base = inc - cnt;
+						const bool mine = lane <= first && base < remaining;
+						uint32_t eland = land, ecnt = 0, efl = 0;
+						if (mine) cl_walk<true>(S, org_dword, start, seg_end, remaining - base, idx + base, eland, ecnt, efl);
+						if (__ballot(mine && efl != 0)) { lerr = 1; break; }
+						const uint64_t done = __ballot(mine && base + ecnt >= remaining);  // the lane that wrote the last entry
+						if (done) {
+							const int le = __ffsll((long long)done) - 1;
+							idx = total;
+							bp = (uint64_t)org_dword * 32u + __shfl(eland, le, 64);
+						} else {  // 64 segments were not enough (or an invalid code came first, caught above)
+							if (first < 64) { lerr = 1; break; }
+							idx += __shfl(inc, 63, 64);
+							bp = (uint64_t)org_dword * 32u + __shfl(land, 63, 64);
 						}
 					}
-					if (lane == 0) { S.rres[0] = (uint32_t)sb; S.rres[1] = (uint32_t)(sb >> 32); S.rres[2] = (uint32_t)sc | (lerr << 16); S.rres[3] = sw; }
+					__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+					if (!lerr) {  // "same as the entry before": every lane owns five consecutive entries
+						uint8_t v[5];
+						uint32_t lastv = 0x100;  // last definite value in this lane's stretch (0x100: none)
+#pragma unroll
+						for (int k = 0; k < 5; k++) {
+							const uint32_t e = (uint32_t)lane * 5 + k;
+							v[k] = e < total ? S.lens[e] : (uint8_t)0;
+							if (e < total && v[k] != CL_PREV) lastv = v[k];
+						}
+						uint32_t carry = lastv;  // inclusive "last definite value up to this lane"
+#pragma unroll
+						for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(carry, d, 64); if (lane >= d && carry == 0x100) carry = o; }
+						uint32_t prev = __shfl_up(carry, 1, 64);
+						if (lane == 0) prev = 0x100;
+#pragma unroll
+						for (int k = 0; k < 5; k++) {
+							const uint32_t e = (uint32_t)lane * 5 + k;
+							if (e < total) {
+								if (v[k] == CL_PREV) { if (prev == 0x100) lerr = 1; else S.lens[e] = (uint8_t)prev; }
+								else prev = v[k];
+							}
+						}
+						if (__ballot(lerr != 0)) lerr = 1;  // a repeat with nothing before it
+					}
+					if (lane == 0) { S.rres[0] = (uint32_t)bp; S.rres[1] = (uint32_t)(bp >> 32); S.rres[2] = lerr; }
 				}
 				__syncthreads();
-				sb = (uint64_t)S.rres[0] | ((uint64_t)S.rres[1] << 32);
-				sc = (int)(S.rres[2] & 0xFFFFu);
-				if (S.rres[2] >> 16) err = CCT_ST_ZLIB;
-				sw = S.rres[3];
-				br.buf = sb; br.cnt = sc; br.bytepos += (uint64_t)(sw - sw0) * 4u;
+				if (S.rres[2]) err = CCT_ST_ZLIB;
+				const uint64_t bend = (uint64_t)S.rres[0] | ((uint64_t)S.rres[1] << 32);
+				br.bytepos = (bend >> 5) * 4u; br.buf = 0; br.cnt = 0;
+				refill(S, br);
+				getbits(br, (int)(bend & 31u));
 			}
 			if (err) break;
 			__syncthreads();
