@@ -103,7 +103,7 @@ struct Context {
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
 	// decode workspaces
-	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images;
+	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	DevBuf h_stage;  // pinned host staging (payloads)
 	// device DEFLATE workspaces
 	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
@@ -521,6 +521,9 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	if ((rc = g_ctx.d_jval.ensure(jper))) return rc;
 	a.ws_role = (uint8_t *)g_ctx.d_role.p; a.ws_slot = (uint32_t *)g_ctx.d_slot.p;
 	a.ws_jord = (uint32_t *)g_ctx.d_jord.p; a.ws_jval = (uint8_t *)g_ctx.d_jval.p;
+	a.pcache_steps = (int)(stride / ((size_t)g_ctx.wg_threads * DEC_SEG) + 2);
+	if ((rc = g_ctx.d_pcache.ensure((size_t)n * a.pcache_steps * g_ctx.wg_threads * sizeof(uint2)))) return rc;
+	a.ws_pcache = (uint2 *)g_ctx.d_pcache.p;
 	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, st));
 	return CCT_OK;
 }
@@ -550,7 +553,7 @@ int cct_shutdown(void)
 	for (auto &kv : g_ctx.luts) { (void)hipFree(kv.second.d_lut); (void)hipFree(kv.second.d_org); (void)hipFree(kv.second.d_orient); (void)hipFree(kv.second.d_pat); }
 	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
 	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
-	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.h_stage,
+	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.d_pcache, &g_ctx.h_stage,
 	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
 	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
 	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs, &g_ctx.z_packed2[0], &g_ctx.z_packed2[1]};

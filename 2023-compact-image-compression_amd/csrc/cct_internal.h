@@ -66,6 +66,9 @@ struct DecArgs {
 	// traversal made of aligned 64x64 tiles (same tables as encode_tiles_kernel): position -> raster offset from LDS
 	const uint32_t *tile_org; const uint8_t *tile_orient; const uint16_t *patterns;
 	int n_tiles, n_orient, width;   // n_tiles == 0: use lut
+	// pass A leaves every lane's view of every parsing step here (pixel ordinal | entry state << 31, value before the
+	// segment) so that pass B does not repeat the workgroup scans: n * pcache_steps * threads entries
+	uint2 *ws_pcache; int pcache_steps;
 };
 
 hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, hipStream_t s);

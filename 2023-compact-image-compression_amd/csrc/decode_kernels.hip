@@ -224,10 +224,13 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	// ------------------------------------------------------------------ pass A: jump tokens
 	uint32_t st_c = 0, npix_c = 0, nj_c = 0;
 	int32_t val_c = 0;
-	for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG) {
+	uint2 *pcache = a.ws_pcache + (size_t)s * a.pcache_steps * T;
+	uint32_t nsteps = 0;
+	for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG, nsteps++) {
 		uint4 w; uint32_t nxt; int nvalid;
 		load_seg(base + (uint32_t)tid * DEC_SEG, w, nxt, nvalid);
 		const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
+		pcache[(size_t)nsteps * T + tid] = make_uint2(min(p.pix_base, 0x7FFFFFFFu) | (p.entry << 31), (uint32_t)p.val_base);
 		if (p.st.njump) {
 			int i = (int)p.entry;
 			uint32_t ord = p.pix_base, k = p.jump_base;
@@ -307,12 +310,14 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 
 	// ------------------------------------------------------------------ pass B: pixels
 	if (!(s_status & CCT_ST_STREAM)) {
-		st_c = 0; npix_c = 0; nj_c = 0; val_c = 0;
-		for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG) {
-			const uint32_t seg_start = base + (uint32_t)tid * DEC_SEG;
+		// every lane re-reads its segments and what pass A's scans told it about them: no barrier in this pass
+		for (uint32_t k = 0; k < nsteps; k++) {
+			const uint32_t seg_start = k * (uint32_t)T * DEC_SEG + (uint32_t)tid * DEC_SEG;
 			uint4 w; uint32_t nxt; int nvalid;
 			load_seg(seg_start, w, nxt, nvalid);
-			const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
+			const uint2 pc = pcache[(size_t)k * T + tid];
+			Parse p;
+			p.entry = pc.x >> 31; p.pix_base = pc.x & 0x7FFFFFFFu; p.val_base = (int32_t)pc.y;
 			int i = (int)p.entry;
 			uint32_t ord = p.pix_base;
 			int32_t val = p.val_base;
@@ -356,7 +361,6 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 			}
 			if (flags) atomicOr(&s_status, flags);
 		}
-		if (npix_c < (uint32_t)N && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
 	}
 	__syncthreads();
 	if (tid == 0) a.status[s] = s_status;
