@@ -198,10 +198,21 @@ def _encode(ptr, on_device, n, w, h, config, dtype, return_info, keep=None):
     status = np.zeros(max(n, 1), dtype=np.uint32)
     psizes = np.zeros(max(n, 1), dtype=np.uint32)
     stats = (_ffi.SliceStats * max(n, 1))()
-    _ffi.check(L.cct_encode_batch(ptr, on_device, n, w, h, bs, flags, eof, magic, ch, bpc,
-                                  out.ctypes.data, out_stride, sizes.ctypes.data, status.ctypes.data,
-                                  psizes.ctypes.data, C.cast(stats, C.c_void_p)))
-    files = [out[i, : sizes[i]].tobytes() for i in range(n)]
+    dev_defl = C.c_int(0)
+    L.cct_get_option(b"device_deflate", C.byref(dev_defl))
+    if defl and dev_defl.value and n > 0:
+        # archive layout: the files come back to back (one compact copy instead of n * out_stride strided bytes)
+        arch = out.reshape(-1)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        _ffi.check(L.cct_encode_batch_packed(ptr, on_device, n, w, h, bs, flags, eof, magic, ch, bpc,
+                                             arch.ctypes.data, arch.size, offs.ctypes.data, sizes.ctypes.data,
+                                             status.ctypes.data, psizes.ctypes.data, C.cast(stats, C.c_void_p)))
+        files = [arch[int(offs[i]): int(offs[i + 1])].tobytes() for i in range(n)]
+    else:
+        _ffi.check(L.cct_encode_batch(ptr, on_device, n, w, h, bs, flags, eof, magic, ch, bpc,
+                                      out.ctypes.data, out_stride, sizes.ctypes.data, status.ctypes.data,
+                                      psizes.ctypes.data, C.cast(stats, C.c_void_p)))
+        files = [out[i, : sizes[i]].tobytes() for i in range(n)]
     if return_info:
         info = [{"payload_len": int(psizes[i]), "n_short": stats[i].n_short, "n_full": stats[i].n_full,
                  "n_jump": stats[i].n_jump, "n_difficult": stats[i].n_difficult,
