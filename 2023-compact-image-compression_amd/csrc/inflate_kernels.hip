@@ -200,18 +200,32 @@ __device__ void build_tables(InfShared &S, int n)
 					if (l == b) code = seen[b] + (uint32_t)__popcll(bal & lt_mask);
 					seen[b] += (uint32_t)__popcll(bal);
 				}
-				if (l == 0) continue;
-				const uint32_t r = __brev(code) >> (32 - l);
-				if (pass == 0) {
-					if (l > FB) atomicMax(&tab[r & ((1u << FB) - 1u)], (uint32_t)(l - FB));
-				} else if (l <= FB) {
-					const uint32_t e = DIST ? d_entry(S, sidx, l) : ll_entry(S, sidx, l);
-					for (uint32_t k = r; k < (1u << FB); k += (1u << l)) tab[k] = e;
-				} else {
-					const uint32_t p = tab[r & ((1u << FB) - 1u)];
-					const uint32_t off = (p >> 8) & 0xFFFFu, kw = p & 15u;
-					const uint32_t e = DIST ? d_entry(S, sidx, l - FB) : ll_entry(S, sidx, l - FB);
-					for (uint32_t k = r >> FB; k < (1u << kw); k += (1u << (l - FB))) sub[off + k] = e;
+				const uint32_t r = l ? __brev(code) >> (32 - l) : 0u;
+				const bool wide = pass == 1 && l != 0 && l <= FB - 6;  // 64 root entries or more
+				if (l != 0) {
+					if (pass == 0) {
+						if (l > FB) atomicMax(&tab[r & ((1u << FB) - 1u)], (uint32_t)(l - FB));
+					} else if (l <= FB) {
+						// a code of l bits owns 2^(FB-l) root entries: up to 32 are written by the symbol's own lane, the
+						// short codes (64 entries and more) by the whole wave below
+						if (!wide) {
+							const uint32_t e = DIST ? d_entry(S, sidx, l) : ll_entry(S, sidx, l);
+							for (uint32_t k = r; k < (1u << FB); k += (1u << l)) tab[k] = e;
+						}
+					} else {
+						const uint32_t p = tab[r & ((1u << FB) - 1u)];
+						const uint32_t off = (p >> 8) & 0xFFFFu, kw = p & 15u;
+						const uint32_t e = DIST ? d_entry(S, sidx, l - FB) : ll_entry(S, sidx, l - FB);
+						for (uint32_t k = r >> FB; k < (1u << kw); k += (1u << (l - FB))) sub[off + k] = e;
+					}
+				}
+				for (uint64_t wm = __ballot(wide); wm; wm &= wm - 1) {  // the short codes of this chunk, one at a time
+					const int src = __ffsll((long long)wm) - 1;
+					const int wl = __shfl(l, src, 64);
+					const uint32_t wr = __shfl(r, src, 64);
+					const int ws = s0 + src;
+					const uint32_t e = DIST ? d_entry(S, ws, wl) : ll_entry(S, ws, wl);
+					for (uint32_t k = wr + ((uint32_t)lane << wl); k < (1u << FB); k += (64u << wl)) tab[k] = e;
 				}
 			}
 			__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
