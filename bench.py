@@ -6,8 +6,8 @@
 
 A step = one pass of the hot path over one batch: 256 device-resident synthetic 12-bit 512x512
 CT slices (BASELINE config 2) are encoded to byte-exact .cct files (HIP transform+pack kernel,
-device DEFLATE bit-identical to zlib level 9, one packed D2H) and those files are decoded back to
-rasters in HBM (host INFLATE, payload H2D, HIP token/scatter kernel).  Three distinct batches rotate so the working set
+device DEFLATE bit-identical to zlib level 9, one packed D2H into a page-locked archive) and those files are
+decoded back to rasters in HBM (archive H2D, device INFLATE, HIP token/scatter kernel).  Three distinct batches rotate so the working set
 (3 x 134 MB) exceeds the 256 MiB Infinity Cache.  Slices shard across GPUs with no data-path
 collective (weak scaling: 256 slices per GPU per step); the only exchange is the all-gather of
 the per-slice compressed sizes over RCCL.
@@ -129,8 +129,8 @@ def main():
 
     batches = make_batches(rank, n)
     d_imgs = [cct_hip.DeviceBuffer.from_numpy(b) for b in batches]
-    # Two buffer sets: while step k is decoded (host INFLATE + decode kernel) step k+1 is already being
-    # encoded (transform+pack + device DEFLATE).  Two host threads drive the C ABI; ctypes drops the GIL.
+    # Three buffer sets: while step k is decoded (device INFLATE + decode kernel on the decode stream) step k+1 is
+    # already being encoded (transform+pack + device DEFLATE).  Host threads drive the C ABI; ctypes drops the GIL.
     out_stride = L.cct_file_bound(W, H, bs)
     NSET = 3
     d_back = [cct_hip.DeviceBuffer(batches[0].nbytes) for _ in range(NSET)]
