@@ -1418,7 +1418,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> (keys_out, vals_out) by hash >> 8
 	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over keys_in, dead after the sort
-	const int gm = (int)std::min<size_t>(256, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
+	const int gm = (int)std::min<size_t>(2048, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
 	hipLaunchKernelGGL(dfl_match_kernel, dim3(gm, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
