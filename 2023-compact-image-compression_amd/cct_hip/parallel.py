@@ -3,16 +3,17 @@ path's only exchange step -- an all-gather of per-slice compressed sizes (RCCL o
 the process group is "nccl"; gloo on CPU for tests).  No pixel or payload byte crosses GPUs:
 slices are independent units (the reference treats them so too, scripts/evaluate.py:107-119).
 """
-import math
-
 import numpy as np
 
 
 def shard_range(n_total, rank, world):
-    """Contiguous slice range [lo, hi) owned by `rank` (ceil(n/G) slices per GPU)."""
-    per = math.ceil(n_total / world) if world > 0 else n_total
-    lo = min(rank * per, n_total)
-    return lo, min(lo + per, n_total)
+    """Contiguous slice range [lo, hi) owned by `rank`: balanced, the first n % G ranks own one slice more
+    (3954 slices over 8 GPUs = shards of 495/494)."""
+    if world <= 0:
+        return 0, n_total
+    per, extra = divmod(n_total, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 def gather_sizes(local_sizes, dist=None, local_rank=0, counts=None):

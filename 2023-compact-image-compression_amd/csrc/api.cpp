@@ -73,6 +73,12 @@ struct ShapeTables {  // everything that depends on (width, height) only; lives 
 	uint32_t *d_org = nullptr;
 	uint8_t *d_orient = nullptr;
 	uint16_t *d_pat = nullptr;
+	// staged pipeline (encode_pipe.hip): every tile is a 16x16 grid of 4x4-pixel traversal blocks
+	bool pipe = false;
+	uint16_t *d_rtab = nullptr;       // n_orient * 256
+	uint32_t *d_otab = nullptr;       // 4 * 16
+	uint32_t *d_ttab = nullptr;       // 16 * 4
+	uint32_t *d_tile_last = nullptr;  // n_orient
 };
 
 struct Context {
@@ -98,10 +104,12 @@ struct Context {
 	int deflate_ways = 1;  // option "deflate_ways" (1..8): 2 is ~8 % faster alone but unstable next to a concurrent decode stream
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
-	int use_tiles = 1;  // option "tile_path": 0 forces the generic LUT-gather kernel
+	int use_tiles = 1;  // option "tile_path": 1 staged pipeline (encode_pipe.hip), 2 one-workgroup-per-slice tile kernel, 0 generic LUT-gather kernel
+	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel)
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
+	DevBuf e_toff, e_pairrec, e_spill;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	// decode workspaces
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	DevBuf h_stage;  // pinned host staging (payloads)
@@ -198,6 +206,91 @@ int ensure_ctx(int device = -1)
 	return CCT_OK;
 }
 
+// Tables of the staged pipeline.  Inside every 64x64 tile the traversal must walk aligned 4x4-pixel blocks (16
+// positions each), and every block must be walked quadrant by quadrant (2x2 pixels, 4 positions each) with quarter 0
+// = top-left or bottom-right quadrant, quarter 2 = the other one, quarter 1 = bottom-left or top-right, quarter 3 = the
+// other one.  The generalized Hilbert curve on power-of-two squares does; anything else keeps the older kernels.
+void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vector<uint32_t> &org,
+                       const std::vector<uint8_t> &orient, ShapeTables &t)
+{
+	t.pipe = false;
+	const int nt = (int)org.size();
+	const int no = t.n_orient;
+	std::vector<uint16_t> rtab((size_t)no * 256, 0xFFFF);
+	std::vector<uint32_t> tile_last(no, 0);
+	std::vector<std::vector<int>> bpat;  // block orientations: raster index (row*4+col) of the 16 positions
+	for (int ti = 0; ti < nt; ti++) {
+		const int32_t *k = O.data() + (size_t)ti * 4096;
+		const int to = orient[ti];
+		for (int b = 0; b < 256; b++) {
+			int lo = k[b * 16];
+			for (int i = 1; i < 16; i++) lo = std::min(lo, k[b * 16 + i]);
+			const int d0 = lo - (int)org[ti];
+			const int by4 = d0 / width, bx4 = d0 % width;
+			if (by4 % 4 || bx4 % 4 || by4 >= 64 || bx4 >= 64) return;
+			std::vector<int> pat(16);
+			for (int i = 0; i < 16; i++) {
+				const int d = k[b * 16 + i] - lo, dy = d / width, dx = d % width;
+				if (dx >= 4 || dy >= 4) return;
+				pat[i] = dy * 4 + dx;
+			}
+			int bo = -1;
+			for (size_t q = 0; q < bpat.size(); q++) if (bpat[q] == pat) { bo = (int)q; break; }
+			if (bo < 0) { if (bpat.size() == 4) return; bpat.push_back(pat); bo = (int)bpat.size() - 1; }
+			const uint16_t ent = (uint16_t)(b | (bo << 8));
+			uint16_t &slot = rtab[(size_t)to * 256 + (by4 / 4) * 16 + bx4 / 4];
+			if (slot != 0xFFFF && slot != ent) return;  // tiles of one orientation must agree
+			slot = ent;
+		}
+		tile_last[to] = (uint32_t)(k[4095] - (int)org[ti]);
+	}
+	for (uint16_t e : rtab) if (e == 0xFFFF) return;
+	std::vector<uint32_t> otab(64, 0);
+	for (size_t bo = 0; bo < bpat.size(); bo++) {
+		const std::vector<int> &pat = bpat[bo];
+		int quad[4];
+		for (int q = 0; q < 4; q++) {
+			const int r = pat[4 * q] / 4, c = pat[4 * q] % 4;
+			quad[q] = (r >> 1) * 2 + (c >> 1);  // 0 TL, 1 TR, 2 BL, 3 BR
+			for (int i = 1; i < 4; i++)
+				if (((pat[4 * q + i] / 4) >> 1) * 2 + ((pat[4 * q + i] % 4) >> 1) != quad[q]) return;
+		}
+		if (!((quad[0] == 0 && quad[2] == 3) || (quad[0] == 3 && quad[2] == 0))) return;
+		if (!((quad[1] == 2 && quad[3] == 1) || (quad[1] == 1 && quad[3] == 2))) return;
+		uint32_t *ot = otab.data() + bo * 16;
+		for (int j = 0; j < 8; j++) {
+			uint32_t sel = 0;
+			for (int h = 0; h < 2; h++) {
+				const int r = pat[2 * j + h] / 4, c = pat[2 * j + h] % 4;
+				const uint32_t byte0 = (uint32_t)((r & 1) * 4 + (c & 1) * 2);  // v_perm source: top dword bytes 0-3, bottom 4-7
+				sel |= (byte0 | ((byte0 + 1) << 8)) << (16 * h);
+			}
+			ot[j] = sel;
+		}
+		ot[8] = (quad[0] == 3 ? 1u : 0u) | (quad[1] == 1 ? 2u : 0u);
+	}
+	// token bytes of a 4-pixel group by its two-byte mask: v_perm selectors over {X: bytes 4-7, P: bytes 0-3}
+	std::vector<uint32_t> ttab(64, 0);
+	for (int f = 0; f < 16; f++) {
+		uint8_t seq[8];
+		int n = 0;
+		for (int px = 0; px < 4; px++) { if (f >> px & 1) seq[n++] = (uint8_t)(4 + px); seq[n++] = (uint8_t)px; }
+		for (int i = n; i < 8; i++) seq[i] = 0x0C;  // constant 0x00
+		ttab[f * 4 + 0] = seq[0] | seq[1] << 8 | seq[2] << 16 | (uint32_t)seq[3] << 24;
+		ttab[f * 4 + 1] = seq[4] | seq[5] << 8 | seq[6] << 16 | (uint32_t)seq[7] << 24;
+		ttab[f * 4 + 2] = (uint32_t)n;
+	}
+	if (hipMalloc(&t.d_rtab, rtab.size() * 2) != hipSuccess) return;
+	if (hipMalloc(&t.d_otab, otab.size() * 4) != hipSuccess) return;
+	if (hipMalloc(&t.d_ttab, ttab.size() * 4) != hipSuccess) return;
+	if (hipMalloc(&t.d_tile_last, tile_last.size() * 4) != hipSuccess) return;
+	if (hipMemcpy(t.d_rtab, rtab.data(), rtab.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_otab, otab.data(), otab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_ttab, ttab.data(), ttab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_tile_last, tile_last.data(), tile_last.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+	t.pipe = true;
+}
+
 // Does the traversal decompose into aligned 64x64 tiles (4096 consecutive positions each)?  If so
 // build what encode_tiles_kernel needs: per tile its origin and which pattern it follows, and per
 // distinct pattern the LDS byte offset (row-XOR-swizzled raster image) of every position.
@@ -245,6 +338,7 @@ void build_tile_tables(const std::vector<int32_t> &O, int width, ShapeTables &t)
 	t.n_tiles = nt;
 	t.n_orient = (int)pats.size();
 	t.tiled = true;
+	build_pipe_tables(O, width, org, orient, t);
 }
 
 int get_tables(int width, int height, const ShapeTables **out)
@@ -375,6 +469,24 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	a.ws_lidx = (uint32_t *)g_ctx.e_lidx.p; a.ws_lmask = (uint64_t *)g_ctx.e_lmask.p; a.ws_lcur = (uint8_t *)g_ctx.e_lcur.p;
 	const ShapeTables *tb = nullptr;
 	if ((flags & CCT_FLAG_FRACTAL) && bs == 16 && g_ctx.use_tiles) { if ((rc = get_tables(width, height, &tb))) return rc; }
+	if (tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && g_ctx.use_tiles == 1 && !g_ctx.dbg_skip) {
+		const int NT = tb->n_tiles;
+		if ((rc = g_ctx.e_role.ensure(per))) return rc;
+		if ((rc = g_ctx.e_toff.ensure((size_t)n * (NT + 1) * 4))) return rc;
+		if ((rc = g_ctx.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
+		if ((rc = g_ctx.e_spill.ensure(per * 4))) return rc;
+		PipeArgs pa{};
+		pa.e = a;
+		pa.tile_org = tb->d_org; pa.tile_orient = tb->d_orient; pa.rtab = tb->d_rtab; pa.otab = tb->d_otab;
+		pa.ttab = tb->d_ttab; pa.tile_last = tb->d_tile_last;
+		pa.n_orient = tb->n_orient; pa.n_tiles = NT; pa.row_pitch = width;
+		pa.ssz = (uint8_t *)g_ctx.e_lcur.p; pa.mask = (uint64_t *)g_ctx.e_lmask.p; pa.roles = (uint8_t *)g_ctx.e_role.p;
+		pa.spec = (uint32_t *)g_ctx.e_lidx.p; pa.toff = (uint32_t *)g_ctx.e_toff.p; pa.pairrec = (uint8_t *)g_ctx.e_pairrec.p;
+		pa.spill_idx = (uint32_t *)g_ctx.e_spill.p;
+		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream));
+		g_ctx.last_path = 1;
+		return CCT_OK;
+	}
 	if (tb && tb->tiled) {
 		bool tile_role_in_lds = true;
 		(void)enc_tiles_lds_bytes(NB, &tile_role_in_lds);
@@ -385,9 +497,11 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 		ta.tile_org = tb->d_org; ta.tile_orient = tb->d_orient; ta.patterns = tb->d_pat;
 		ta.n_orient = tb->n_orient; ta.n_tiles = tb->n_tiles; ta.row_pitch = width;
 		HIP_TRY(launch_encode_tiles(ta, n, g_ctx.stream));
+		g_ctx.last_path = 2;
 		return CCT_OK;
 	}
 	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
+	g_ctx.last_path = 0;
 	return CCT_OK;
 }
 
@@ -1228,7 +1342,7 @@ int cct_set_option(const char *key, int value)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
-	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = (value >= 0 && value <= 2) ? value : 1; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
@@ -1245,6 +1359,7 @@ int cct_get_option(const char *key, int *value)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
+	if (!strcmp(key, "last_encode_path")) { *value = g_ctx.last_path; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }

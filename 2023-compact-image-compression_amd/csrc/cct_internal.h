@@ -47,6 +47,30 @@ struct TileEncArgs {
 size_t enc_tiles_lds_bytes(int NB, bool *role_in_lds);
 hipError_t launch_encode_tiles(const TileEncArgs &ta, int n, hipStream_t s);
 
+// staged pipeline (encode_pipe.hip): analyse -> resolve -> pack, tile-parallel, same applicability as the tile path
+// up to 1024x1024 (larger tiled shapes stay on encode_tiles_kernel)
+constexpr int PIPE_MAX_NB = 65536;          // blocks per slice (the resolve kernel keeps role[] in LDS)
+constexpr int PIPE_PAIR_REC = 80;           // bytes per meshed-pair record: jump byte + up to 64 token bytes, padded to 16
+constexpr uint32_t CCT_ST_INTERNAL = 0x80000000u;  // the kernels disagree about a size: a bug, never a data property
+struct PipeArgs {
+	EncArgs e;                   // e.lut must be the traversal table
+	const uint32_t *tile_org;    // n_tiles: raster index of each tile's top-left pixel
+	const uint8_t *tile_orient;  // n_tiles: tile orientation (index into rtab / tile_last)
+	const uint16_t *rtab;        // n_orient * 256: raster block by*16+bx of a tile -> traversal block index | block orientation << 8
+	const uint32_t *otab;        // 4 * 16 dwords per block orientation: eight v_perm selectors, quadrant choice bits
+	const uint32_t *ttab;        // 16 * 4 dwords: token byte selectors and length for the 16 two-byte masks of a 4-pixel group
+	const uint32_t *tile_last;   // n_orient: raster offset inside the tile of the tile's last traversal position
+	int n_orient, n_tiles, row_pitch;
+	uint8_t *ssz;                // n * NB: token bytes of every block emitted alone after its traversal predecessor | 0x80 if difficult
+	uint64_t *mask;              // n * NB: candidate fit masks, valid for difficult blocks
+	uint8_t *roles;              // n * NB: the block partition
+	uint32_t *spec;              // n * NB: leaders: pair record << 8 | group bytes; blocks after a meshed block: predecessor pixel
+	uint32_t *toff;              // n * (n_tiles + 1): payload offset of every tile's first token, then the token total
+	uint8_t *pairrec;            // n * (NB / 2) * PIPE_PAIR_REC
+	uint32_t *spill_idx;         // n * NB: ordered difficult-block list beyond the LDS capacity of the resolve kernel
+};
+hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s);
+
 size_t enc_lds_bytes(int NB, bool *role_in_lds);
 hipError_t launch_encode(const EncArgs &a, int n, int block_size, int threads, hipStream_t s);
 

@@ -63,4 +63,5 @@ def test_shard_range_covers_everything():
                 lo, hi = shard_range(n, r, world)
                 got.extend(range(lo, hi))
             assert got == list(range(n))
-    assert shard_range(3954, 0, 8) == (0, 495) and shard_range(3954, 7, 8) == (3465, 3954)
+    assert shard_range(3954, 0, 8) == (0, 495) and shard_range(3954, 2, 8) == (990, 1484) and shard_range(3954, 7, 8) == (3460, 3954)
+    assert sorted({hi - lo for lo, hi in (shard_range(3954, r, 8) for r in range(8))}) == [494, 495]
