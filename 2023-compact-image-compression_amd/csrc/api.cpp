@@ -75,7 +75,8 @@ struct ShapeTables {  // everything that depends on (width, height) only; lives 
 	uint16_t *d_pat = nullptr;
 	// staged pipeline (encode_pipe.hip): every tile is a 16x16 grid of 4x4-pixel traversal blocks
 	bool pipe = false;
-	uint16_t *d_rtab = nullptr;       // n_orient * 256
+	uint32_t *d_ptab = nullptr;       // n_orient * 128 * 4
+	uint32_t *d_btab = nullptr;       // n_orient * 256
 	uint32_t *d_otab = nullptr;       // 4 * 16
 	uint32_t *d_ttab = nullptr;       // 16 * 4
 	uint32_t *d_tile_last = nullptr;  // n_orient
@@ -105,6 +106,8 @@ struct Context {
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 1 staged pipeline (encode_pipe.hip), 2 one-workgroup-per-slice tile kernel, 0 generic LUT-gather kernel
+	int pipe_tpw = 0, pipe_timing = 0;  // tuning options "pipe_tpw", "pipe_timing" (then "pipe_us_k1/k2/k3" hold the last kernel times)
+	float pipe_us[4] = {0, 0, 0, 0};
 	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel)
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	// encode workspaces
@@ -245,6 +248,33 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 		tile_last[to] = (uint32_t)(k[4095] - (int)org[ti]);
 	}
 	for (uint16_t e : rtab) if (e == 0xFFFF) return;
+	// per-lane entries of a tile workgroup and the block table of the mask kernel
+	std::vector<uint32_t> ptab((size_t)no * 128 * 4, 0), btab((size_t)no * 256, 0);
+	{
+		std::vector<int> done(no, 0);
+		for (int ti = 0; ti < nt; ti++) {
+			const int to = orient[ti];
+			if (done[to]) continue;
+			done[to] = 1;
+			const int32_t *k = O.data() + (size_t)ti * 4096;
+			for (int lane = 0; lane < 128; lane++) {
+				const int by = lane >> 3, bxp = lane & 7;
+				uint32_t *e = ptab.data() + ((size_t)to * 128 + lane) * 4;
+				e[0] = (uint32_t)rtab[(size_t)to * 256 + by * 16 + 2 * bxp] | (uint32_t)rtab[(size_t)to * 256 + by * 16 + 2 * bxp + 1] << 16;
+				for (int h = 0; h < 2; h++) {
+					const int kb = (int)((e[0] >> (16 * h)) & 0xFF);
+					e[1 + h] = kb == 0 ? 0xFFFFFFFFu : (uint32_t)(k[kb * 16 - 1] - (int)org[ti]);
+				}
+			}
+			for (int b = 0; b < 256; b++) {
+				int lo = k[b * 16];
+				for (int i = 1; i < 16; i++) lo = std::min(lo, k[b * 16 + i]);
+				uint32_t bo = 0;
+				for (int r = 0; r < 256; r++) if ((rtab[(size_t)to * 256 + r] & 0xFF) == b) bo = rtab[(size_t)to * 256 + r] >> 8;
+				btab[(size_t)to * 256 + b] = (uint32_t)(lo - (int)org[ti]) | bo << 24;
+			}
+		}
+	}
 	std::vector<uint32_t> otab(64, 0);
 	for (size_t bo = 0; bo < bpat.size(); bo++) {
 		const std::vector<int> &pat = bpat[bo];
@@ -280,11 +310,13 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 		ttab[f * 4 + 1] = seq[4] | seq[5] << 8 | seq[6] << 16 | (uint32_t)seq[7] << 24;
 		ttab[f * 4 + 2] = (uint32_t)n;
 	}
-	if (hipMalloc(&t.d_rtab, rtab.size() * 2) != hipSuccess) return;
+	if (hipMalloc(&t.d_ptab, ptab.size() * 4) != hipSuccess) return;
+	if (hipMalloc(&t.d_btab, btab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_otab, otab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_ttab, ttab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_tile_last, tile_last.size() * 4) != hipSuccess) return;
-	if (hipMemcpy(t.d_rtab, rtab.data(), rtab.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_ptab, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMemcpy(t.d_btab, btab.data(), btab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_otab, otab.data(), otab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_ttab, ttab.data(), ttab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_tile_last, tile_last.data(), tile_last.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
@@ -477,13 +509,14 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 		if ((rc = g_ctx.e_spill.ensure(per * 4))) return rc;
 		PipeArgs pa{};
 		pa.e = a;
-		pa.tile_org = tb->d_org; pa.tile_orient = tb->d_orient; pa.rtab = tb->d_rtab; pa.otab = tb->d_otab;
+		pa.tile_org = tb->d_org; pa.tile_orient = tb->d_orient; pa.ptab = tb->d_ptab; pa.btab = tb->d_btab; pa.otab = tb->d_otab;
 		pa.ttab = tb->d_ttab; pa.tile_last = tb->d_tile_last;
 		pa.n_orient = tb->n_orient; pa.n_tiles = NT; pa.row_pitch = width;
 		pa.ssz = (uint8_t *)g_ctx.e_lcur.p; pa.mask = (uint64_t *)g_ctx.e_lmask.p; pa.roles = (uint8_t *)g_ctx.e_role.p;
 		pa.spec = (uint32_t *)g_ctx.e_lidx.p; pa.toff = (uint32_t *)g_ctx.e_toff.p; pa.pairrec = (uint8_t *)g_ctx.e_pairrec.p;
 		pa.spill_idx = (uint32_t *)g_ctx.e_spill.p;
-		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream));
+		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
+		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream, &tune));
 		g_ctx.last_path = 1;
 		return CCT_OK;
 	}
@@ -1344,6 +1377,8 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = (value >= 0 && value <= 2) ? value : 1; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
+	if (!strcmp(key, "pipe_tpw")) { g_ctx.pipe_tpw = value; return CCT_OK; }
+	if (!strcmp(key, "pipe_timing")) { g_ctx.pipe_timing = value; return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
@@ -1360,6 +1395,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
 	if (!strcmp(key, "last_encode_path")) { *value = g_ctx.last_path; return CCT_OK; }
+	if (!strncmp(key, "pipe_us_k", 9) && key[9] >= '1' && key[9] <= '4') { *value = (int)(g_ctx.pipe_us[key[9] - '1'] * 10.0f); return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }

@@ -56,7 +56,11 @@ struct PipeArgs {
 	EncArgs e;                   // e.lut must be the traversal table
 	const uint32_t *tile_org;    // n_tiles: raster index of each tile's top-left pixel
 	const uint8_t *tile_orient;  // n_tiles: tile orientation (index into rtab / tile_last)
-	const uint16_t *rtab;        // n_orient * 256: raster block by*16+bx of a tile -> traversal block index | block orientation << 8
+	const uint32_t *ptab;        // n_orient * 128 entries of 4 dwords, one per lane of a tile workgroup (lane = block row * 8 + block pair):
+	                             //   [0] traversal block index | orientation << 8 of the left block, the same << 16 for the right block
+	                             //   [1], [2] raster offset inside the tile of the pixel that precedes the left / right block in
+	                             //   traversal order (0xFFFFFFFF: the block opens the tile)
+	const uint32_t *btab;        // n_orient * 256: traversal block of a tile -> raster offset of its top-left pixel | orientation << 24
 	const uint32_t *otab;        // 4 * 16 dwords per block orientation: eight v_perm selectors, quadrant choice bits
 	const uint32_t *ttab;        // 16 * 4 dwords: token byte selectors and length for the 16 two-byte masks of a 4-pixel group
 	const uint32_t *tile_last;   // n_orient: raster offset inside the tile of the tile's last traversal position
@@ -69,7 +73,11 @@ struct PipeArgs {
 	uint8_t *pairrec;            // n * (NB / 2) * PIPE_PAIR_REC
 	uint32_t *spill_idx;         // n * NB: ordered difficult-block list beyond the LDS capacity of the resolve kernel
 };
-hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s);
+struct PipeTune {   // tuning runs only
+	int tpw;           // tiles per analyse workgroup (0: default)
+	float *times_us;   // if set: the four kernels are timed with events (synchronises): [analyse, masks, resolve, pack]
+};
+hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const PipeTune *tune = nullptr);
 
 size_t enc_lds_bytes(int NB, bool *role_in_lds);
 hipError_t launch_encode(const EncArgs &a, int n, int block_size, int threads, hipStream_t s);

@@ -1,24 +1,30 @@
-// CompaCT encode, stage (i) as a tile-parallel pipeline of three kernels (block_size 16, traversal made of aligned
+// CompaCT encode, stage (i) as a tile-parallel pipeline of four kernels (block_size 16, traversal made of aligned
 // 64x64 tiles whose 4x4-pixel blocks are traversal blocks: every power-of-two square up to 1024x1024).
 //
-//   K1 pipe_analyse_kernel   grid = slices x groups of tiles, 128 lanes = one tile per step
+//   K1a pipe_analyse_kernel  grid = slices x groups of tiles, 128 lanes = one tile per step, no LDS traffic, no barrier
 //        HBM -> VGPR   16 bytes per lane and row: a lane owns a PAIR of horizontally adjacent 4x4 blocks (8x4 pixels),
-//                      a wave-instruction reads eight full 128-byte lines
+//                      a wave-instruction reads eight full 128-byte lines; the next tile's rows are in flight meanwhile
 //        in registers  the 16 pixels of a block are put in traversal order with v_perm_b32 (selectors per block
-//                      orientation) -- no per-pixel LDS gather
-//        VGPR -> LDS   traversal-ordered tile image (32 bytes per block), three tiles deep for the mesh look-ahead
+//                      orientation) -- no per-pixel gather
 //        analysis      packed 16-bit deltas, |delta| > 64 counts (cluster.py:30-59), token bytes of the block if it is
-//                      emitted alone (core.py:316-323), candidate fit masks of the difficult blocks (cluster.py:122-158)
-//   K2 pipe_resolve_kernel   one workgroup per slice: greedy first fit over the islands of difficult blocks
+//                      emitted alone (core.py:316-323) -> one byte per block (size | difficult << 7)
+//   K1b pipe_masks_kernel    one wave per tile: candidate fit masks of its difficult blocks (cluster.py:122-158), one
+//                      candidate per lane, the difficult block's thresholds in SGPRs
+//   K2  pipe_resolve_kernel  one workgroup per slice: greedy first fit over the islands of difficult blocks
 //                      (cluster.py:79-190), the token bytes of the meshed pairs, the predecessor pixel of every block that
 //                      follows a meshed block, payload offset of every tile
-//   K3 pipe_pack_kernel      grid = slices x tiles: same front end, tokens of every block formed four pixels at a time
+//   K3  pipe_pack_kernel     grid = slices x tiles: same front end, tokens of every block formed four pixels at a time
 //                      with byte permutes through a 16-entry table, OR-ed into a zeroed LDS image of the tile's payload
 //                      bytes at their final offsets, flushed with aligned 16-byte stores
 //
 // Probed on the MI355X (tools/microbench/lds_probe.hip): ds_write_b8, ds_write_b32 and ds_or_b32 all cost ~4.5 cycles per
 // wave-instruction, LDS stores at addresses that are not multiples of the access size ~79 cycles, and 8-byte-per-lane
 // block-shaped global reads reach 4.5 TB/s where 16-byte-per-lane full lines reach 6.4 TB/s.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "cct_internal.h"
 #include "../../include/compact_hip.h"
 
@@ -86,6 +92,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 	return v;
 }
 
+// ---- diagnostic build only (CCT_PIPE_STAMPS=1): cycles per phase, summed per wave, written to a buffer of their own
+struct Stamps {
+	uint64_t acc[8];
+	uint64_t last;
+};
+template <bool ON>
+__device__ __forceinline__ void stamp_init(Stamps &st)
+{
+	if (ON) { for (int i = 0; i < 8; i++) st.acc[i] = 0; st.last = __builtin_amdgcn_s_memtime(); }
+}
+template <bool ON>
+__device__ __forceinline__ void stamp(Stamps &st, int phase)
+{
+	if (ON) {
+		__builtin_amdgcn_sched_barrier(0);
+		const uint64_t t = __builtin_amdgcn_s_memtime();
+		st.acc[phase] += t - st.last;
+		st.last = t;
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+template <bool ON>
+__device__ __forceinline__ void stamp_store(const Stamps &st, uint64_t *buf, int slot)
+{
+	if (ON && (threadIdx.x & 63) == 0 && buf)
+		for (int i = 0; i < 8; i++) buf[(size_t)slot * 8 + i] = st.acc[i];
+}
+
 // ---- front end shared by K1 and K3 ---------------------------------------------------------------------
 // Rows 0..3 of a 4x4 block as (columns 0-1, columns 2-3) dwords -> its 16 pixels in traversal order.
 // ot: the block orientation's table (eight selectors, then the quadrant choice bits).  A 4x4 block is walked quadrant
@@ -122,14 +156,7 @@ __device__ __forceinline__ int px16(const uint32_t d[8], int i) { return (int)((
 __device__ __forceinline__ bool tok_two(int dlt) { return (uint32_t)(dlt + 63) > 127u; }
 __device__ __forceinline__ bool seg_large(int dlt) { return (uint32_t)(dlt + 64) > 128u; }
 
-// ---- K1 ---------------------------------------------------------------------------------------------------
-constexpr int K1_DLIN = 0;                        // 3 x 8192
-constexpr int K1_RTAB = 3 * TILE_BYTES;           // TILE_MAX_ORIENT x 512
-constexpr int K1_OTAB = K1_RTAB + TILE_MAX_ORIENT * 512;  // 256
-constexpr int K1_LST = K1_OTAB + 256;             // 3 x 2 x 128 u16
-constexpr int K1_MISC = K1_LST + 3 * 2 * 128 * 2; // lcnt[3][2], halo flag
-constexpr int K1_LDS = K1_MISC + 64;
-
+// ---- K1a ---------------------------------------------------------------------------------------------------
 // token bytes and segmentation counts of one block; packed path: every pixel of the wave's blocks < 0x4000
 template <bool SGN>
 __device__ __forceinline__ void analyse_block(const uint32_t d[8], uint32_t pv, bool wide, bool first_of_slice,
@@ -169,62 +196,13 @@ __device__ __forceinline__ void analyse_block(const uint32_t d[8], uint32_t pv, 
 	if (first_of_slice) enter = 0;  // P[0] = 0: the first pixel has no entering transition (cluster.py:33)
 }
 
-// fit mask of difficult block A against the 63 candidates (one per lane; lane j looks at block i + j): cluster.py:122-158
-template <bool SGN>
-__device__ __forceinline__ uint64_t fit_mask(const LDS(uint16_t) *ap, const LDS(uint16_t) *bp, bool valid, uint32_t cur, bool block0)
+template <bool SGN, bool STAMP>
+__global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, uint64_t *stamps)
 {
-	const u32x4 a0 = *(const LDS(u32x4) *)(ap), a1 = *(const LDS(u32x4) *)(ap + 8);
-	const u32x4 b0 = *(const LDS(u32x4) *)(bp), b1 = *(const LDS(u32x4) *)(bp + 8);
-	const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-	const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-	uint32_t hi_or = 0;
-#pragma unroll
-	for (int q = 0; q < 8; q++) hi_or |= aw[q] | bw[q];
-	const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
-	uint32_t up;
-	if (small) {
-		// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences are
-		// exact: count the NEGATIVE results of B[t] - (A[t] + 65) and (A[t+1] - 65) - B[t]
-		const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
-		uint32_t neg = 0;
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[q], pk_add(aw[q], K65))));
-			const uint32_t an = (q < 7) ? __builtin_amdgcn_alignbit(aw[q + 1], aw[q], 16) : (aw[7] >> 16);
-			uint32_t hi = pk_sub(an, K65);
-			if (q == 7) hi |= 0xFFFF0000u;  // t = 15 has no successor: -1 - B[15] is always negative
-			neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(hi, bw[q])));
-		}
-		up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
-	} else {
-		up = 0;
-		int bprev = 0;
-#pragma unroll
-		for (int t = 0; t < 16; t++) {
-			int av = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
-			if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
-			if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
-			up += (bv - av >= 65) ? 1u : 0u;
-			bprev = bv;
-		}
-	}
-	// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
-	const bool fit = valid && (block0 ? true : ((up + 1u) < (cur - 2u)));
-	return __ballot(fit);
-}
-
-template <bool SGN>
-__global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw)
-{
-	__shared__ __attribute__((aligned(16))) uint8_t smem[K1_LDS];
-	LDS(uint8_t) *dlin = (LDS(uint8_t) *)(smem + K1_DLIN);
-	LDS(uint32_t) *rtab = (LDS(uint32_t) *)(smem + K1_RTAB);
-	LDS(uint32_t) *otab = (LDS(uint32_t) *)(smem + K1_OTAB);
-	LDS(uint16_t) *lst = (LDS(uint16_t) *)(smem + K1_LST);
-	LDS(uint32_t) *lcnt = (LDS(uint32_t) *)(smem + K1_MISC);
-	LDS(uint32_t) *halo_flag = lcnt + 8;
-
-	const int tid = threadIdx.x, lane = tid & 63;
+	Stamps st;
+	stamp_init<STAMP>(st);
+	__shared__ __attribute__((aligned(16))) uint32_t otab[64];
+	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
 	const int wps = (NT + tpw - 1) / tpw;
@@ -236,111 +214,209 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw)
 	uint8_t *ssz = a.ssz + (size_t)sl * NB;
 	uint64_t *gmask = a.mask + (size_t)sl * NB;
 	const int pitch = a.row_pitch;
+	const u32x4 *ptab = reinterpret_cast<const u32x4 *>(a.ptab);
 
 	// lane's region of a tile: block row by (0..15), block pair bxp (0..7)
 	const int by = tid >> 3, bxp = tid & 7;
 	const size_t reg_off = (size_t)(by * 4) * pitch + bxp * 8;
-	auto load_tile = [&](int tile, u32x4 r[4]) {
+	auto load_rows = [&](int tile, u32x4 r[4]) {
 		const uint16_t *p = img + a.tile_org[tile] + reg_off;
 #pragma unroll
 		for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
 	};
-	u32x4 r[4];
-	load_tile(t0, r);
-	// pixel before the first tile of this workgroup (the slice starts at 0, core.py:278)
-	uint32_t first_prev = 0;
-	if (t0 > 0) first_prev = img[a.tile_org[t0 - 1] + a.tile_last[a.tile_orient[t0 - 1]]];
-	{
-		const int nr = a.n_orient * 128;
-		for (int i = tid; i < nr; i += PW) rtab[i] = reinterpret_cast<const uint32_t *>(a.rtab)[i];
-		if (tid < 64) otab[tid] = a.otab[tid];
-		if (tid < 9) lcnt[tid] = 0;
-	}
+	// pixels before the lane's two blocks (traversal order); a block that opens its tile follows the previous tile's last pixel
+	auto load_prev = [&](int tile, const u32x4 &ent, uint32_t &pa, uint32_t &pb) {
+		const uint32_t org = a.tile_org[tile];
+		const uint32_t porg = tile > 0 ? a.tile_org[tile - 1] + a.tile_last[a.tile_orient[tile - 1]] : 0u;
+		pa = img[ent.y != 0xFFFFFFFFu ? org + ent.y : porg];
+		pb = img[ent.z != 0xFFFFFFFFu ? org + ent.z : porg];
+	};
+	u32x4 r[4], ent;
+	load_rows(t0, r);
+	ent = ptab[(int)a.tile_orient[t0] * PW + tid];
+	if (tid < 64) otab[tid] = a.otab[tid];
+	uint32_t pvA, pvB;
+	load_prev(t0, ent, pvA, pvB);
 	__syncthreads();
+	stamp<STAMP>(st, 0);
 
-	uint32_t dA[8], dB[8];   // the lane's two blocks of the current tile, traversal order
-	int kA = 0, kB = 0;
-	bool halo = false;
-	for (int s = 0; s <= nT; s++) {
+	for (int s = 0; s < nT; s++) {
 		const int tile = t0 + s;
-		const bool body = s < nT;
-		const bool have = body || halo;
-		LDS(uint8_t) *slot = dlin + (s % 3) * TILE_BYTES;
-		if (have) {
-			const uint32_t e2 = rtab[(int)a.tile_orient[tile] * 128 + tid];  // entries of the left and the right block
-			kA = (int)(e2 & 0xFFu); kB = (int)((e2 >> 16) & 0xFFu);
-			permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((e2 >> 8) & 3u) * 16, dA);
-			permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((e2 >> 24) & 3u) * 16, dB);
-			*(LDS(u32x4) *)(slot + kA * 32) = (u32x4){dA[0], dA[1], dA[2], dA[3]};
-			*(LDS(u32x4) *)(slot + kA * 32 + 16) = (u32x4){dA[4], dA[5], dA[6], dA[7]};
-			*(LDS(u32x4) *)(slot + kB * 32) = (u32x4){dB[0], dB[1], dB[2], dB[3]};
-			*(LDS(u32x4) *)(slot + kB * 32 + 16) = (u32x4){dB[4], dB[5], dB[6], dB[7]};
+		uint32_t dA[8], dB[8];
+		const uint32_t e2 = ent.x;
+		const int kA = (int)(e2 & 0xFFu), kB = (int)((e2 >> 16) & 0xFFu);
+		permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, (const LDS(uint32_t) *)otab + ((e2 >> 8) & 3u) * 16, dA);
+		permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, (const LDS(uint32_t) *)otab + ((e2 >> 24) & 3u) * 16, dB);
+		const uint32_t cpA = pvA, cpB = pvB;
+		if (s + 1 < nT) {  // the next tile's rows are in flight across the analysis below
+			load_rows(tile + 1, r);
+			ent = ptab[(int)a.tile_orient[tile + 1] * PW + tid];
 		}
-		if (s + 1 < nT) load_tile(tile + 1, r);  // in flight across the analysis below
-		lds_barrier();                           // lgkmcnt(0) only: the prefetch stays in flight
-		if (body) {
-			// ---- analysis of the lane's two blocks (cluster.py:30-59, core.py:316-323)
-			uint32_t orall = 0;
+		stamp<STAMP>(st, 1);
+		uint32_t orall = cpA | cpB;
 #pragma unroll
-			for (int j = 0; j < 8; j++) orall |= dA[j] | dB[j];
-			const bool wide = SGN || __any((orall & 0xC000C000u) != 0);
-			LDS(uint8_t) *pslot = dlin + ((s + 2) % 3) * TILE_BYTES;
-			uint32_t ndiff_lane[2] = {0, 0}, cur_lane[2] = {0, 0};
+		for (int j = 0; j < 8; j++) orall |= dA[j] | dB[j];
+		const bool wide = SGN || __any((orall & 0xC000C000u) != 0);
 #pragma unroll
-			for (int h = 0; h < 2; h++) {
-				const int k = h ? kB : kA;
-				const uint32_t *d = h ? dB : dA;
-				uint32_t pv;
-				if (k > 0) pv = *(const LDS(uint16_t) *)(slot + k * 32 - 2);
-				else if (s > 0) pv = *(const LDS(uint16_t) *)(pslot + TILE_BYTES - 2);
-				else pv = first_prev;
-				const bool first_of_slice = (tile == 0 && k == 0);
-				uint32_t n2, chg, enter;
-				analyse_block<SGN>(d, pv, wide, first_of_slice, n2, chg, enter);
-				const bool difficult = seg && chg >= 8u;                      // cluster.py:58
-				ssz[tile * 256 + k] = (uint8_t)((16u + n2) | (difficult ? 0x80u : 0u));
-				ndiff_lane[h] = difficult ? 1u : 0u;
-				cur_lane[h] = chg + enter;                                    // cluster.py:110
-			}
-			// difficult blocks of this tile: per-wave lists, order irrelevant for the masks
-			const uint64_t balA = __ballot(ndiff_lane[0] != 0), balB = __ballot(ndiff_lane[1] != 0);
-			const uint32_t nA = (uint32_t)__popcll(balA);
-			LDS(uint16_t) *mylst = lst + ((s % 3) * 2 + wave) * 128;
-			const uint64_t below = (1ull << lane) - 1ull;
-			if (ndiff_lane[0]) mylst[__popcll(balA & below)] = (uint16_t)(kA | (cur_lane[0] << 8));
-			if (ndiff_lane[1]) mylst[nA + __popcll(balB & below)] = (uint16_t)(kB | (cur_lane[1] << 8));
-			if (lane == 0) lcnt[(s % 3) * 2 + wave] = nA + (uint32_t)__popcll(balB);
-			if (s == nT - 1 && t0 + nT < NT) {
-				// look-ahead of the last tile reaches into the next workgroup's first tile: fetch it only if needed
-				const bool needA = ndiff_lane[0] && kA >= 193, needB = ndiff_lane[1] && kB >= 193;
-				if (__any(needA || needB) && lane == 0) *halo_flag = 1;
+		for (int h = 0; h < 2; h++) {
+			const int k = h ? kB : kA;
+			const uint32_t *d = h ? dB : dA;
+			const bool first_of_slice = (tile == 0 && k == 0);
+			const uint32_t pv = first_of_slice ? 0u : (h ? cpB : cpA);  // the slice starts from pixel value 0 (core.py:278)
+			uint32_t n2, chg, enter;
+			analyse_block<SGN>(d, pv, wide, first_of_slice, n2, chg, enter);
+			const bool difficult = seg && chg >= 8u;                      // cluster.py:58
+			const int b = tile * 256 + k;
+			ssz[b] = (uint8_t)((16u + n2) | (difficult ? 0x80u : 0u));
+			if (difficult) gmask[b] = (uint64_t)(chg + enter);            // cluster.py:110; K1b replaces it with the mask
+		}
+		stamp<STAMP>(st, 2);
+		if (s + 1 < nT) load_prev(tile + 1, ent, pvA, pvB);
+		stamp<STAMP>(st, 3);
+	}
+	stamp_store<STAMP>(st, stamps, blockIdx.x * 2 + wave);
+}
+
+// ---- K1b --------------------------------------------------------------------------------------------------
+// MQ workgroups of MW waves per slice.  Every workgroup lists the slice's difficult blocks from the K1a bytes (ordered,
+// in LDS) and its waves take them round-robin, so that the mask work is spread evenly whatever tiles it sits in.  For a
+// difficult block i lane j fetches block i + j (four 8-byte row segments, L2 hits: K1a has just streamed them), puts it
+// in traversal order and counts the positive jumps of the interleaved order A0 B0 A1 B1 ... (cluster.py:131-153); lane 0
+// holds block A itself, whose terms go to SGPRs.  The fetch of the next entry is in flight while this one is evaluated.
+constexpr int MW = 8, MQ = 4;          // waves per workgroup, workgroups per slice
+constexpr int MSEG = 16384;            // blocks listed per pass (the list holds 16-bit indices)
+constexpr int K1B_LIST = 0;            // MSEG u16
+constexpr int K1B_BTAB = MSEG * 2;     // TILE_MAX_ORIENT x 256 u32
+constexpr int K1B_TILE = K1B_BTAB + TILE_MAX_ORIENT * 1024;  // 256 u32: tile origin | orientation << 28
+constexpr int K1B_OTAB = K1B_TILE + 1024;
+constexpr int K1B_MISC = K1B_OTAB + 256;
+constexpr int K1B_LDS = K1B_MISC + 64;
+
+template <bool SGN>
+__global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t smem[K1B_LDS];
+	LDS(uint16_t) *lst = (LDS(uint16_t) *)(smem + K1B_LIST);
+	LDS(uint32_t) *btab = (LDS(uint32_t) *)(smem + K1B_BTAB);
+	LDS(uint32_t) *ltile = (LDS(uint32_t) *)(smem + K1B_TILE);
+	LDS(uint32_t) *otab = (LDS(uint32_t) *)(smem + K1B_OTAB);
+	LDS(uint32_t) *misc = (LDS(uint32_t) *)(smem + K1B_MISC);
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
+	const int sl = blockIdx.x / MQ, q = blockIdx.x % MQ;
+	const uint8_t *ssz = a.ssz + (size_t)sl * NB;
+	const uint16_t *img = a.e.images + (size_t)sl * N;
+	uint64_t *gmask = a.mask + (size_t)sl * NB;
+	const int pitch = a.row_pitch;
+	for (int i = tid; i < a.n_orient * 256; i += 64 * MW) btab[i] = a.btab[i];
+	for (int i = tid; i < NT; i += 64 * MW) ltile[i] = a.tile_org[i] | (uint32_t)a.tile_orient[i] << 28;
+	if (tid < 64) otab[tid] = a.otab[tid];
+
+	struct Rows { uint2 r0, r1, r2, r3; uint32_t bt; };
+	// rows of candidate block (b + lane) of the slice; lanes without a candidate re-read block b
+	auto fetch = [&](int b, Rows &o, bool &valid) {
+		valid = lane >= 1 && b + lane < NB;
+		const int c = (lane == 0 || valid) ? b + lane : b;
+		const uint32_t tl = ltile[c >> 8];
+		o.bt = btab[(tl >> 28) * 256 + (c & 255)];
+		const uint16_t *p = img + (tl & 0x0FFFFFFFu) + (o.bt & 0xFFFFFFu);
+		o.r0 = *reinterpret_cast<const uint2 *>(p);
+		o.r1 = *reinterpret_cast<const uint2 *>(p + pitch);
+		o.r2 = *reinterpret_cast<const uint2 *>(p + 2 * (size_t)pitch);
+		o.r3 = *reinterpret_cast<const uint2 *>(p + 3 * (size_t)pitch);
+	};
+
+	for (int seg = 0; seg < NB; seg += MSEG) {
+		const int nseg = min(MSEG, NB - seg);
+		// ---- ordered list of the segment's difficult blocks: 32 bytes per lane
+		const int per = max(1, nseg / (64 * MW));  // bytes per lane: 32 at 16384 blocks, 8 at 4096, 2 at 1024, 1 at 512
+		uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		if (per >= 32) {
+			const u32x4 v0 = *reinterpret_cast<const u32x4 *>(ssz + seg + tid * 32), v1 = *reinterpret_cast<const u32x4 *>(ssz + seg + tid * 32 + 16);
+			w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+		} else if (per >= 8) {
+			const uint2 v = *reinterpret_cast<const uint2 *>(ssz + seg + tid * 8);
+			w[0] = v.x; w[1] = v.y;
+		} else if (per >= 2) {
+			w[0] = *reinterpret_cast<const uint16_t *>(ssz + seg + tid * 2);
+		} else if (tid < nseg) {
+			w[0] = ssz[seg + tid];
+		}
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) { w[j] &= 0x80808080u; cnt += (uint32_t)__popc(w[j]); }
+		const uint32_t inc = wave_incl_scan(cnt);
+		if (lane == 63) misc[wave] = inc;
+		__syncthreads();
+		uint32_t pos = inc - cnt, total = 0;
+#pragma unroll
+		for (int v = 0; v < MW; v++) { const uint32_t t = misc[v]; if (v < wave) pos += t; total += t; }
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			uint32_t m = w[j];
+			while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1; lst[pos++] = (uint16_t)(tid * per + j * 4 + (bit >> 3)); }
+		}
+		__syncthreads();
+		// ---- this wave's entries: first + k * stride
+		const int first = q * MW + wave, stride = MQ * MW;
+		for (int e0 = first; e0 < (int)total; e0 += 64 * stride) {
+			const int ne = min(64, ((int)total - e0 + stride - 1) / stride);
+			uint32_t idxs = 0, curs = 0;
+			if (lane < ne) { idxs = lst[e0 + lane * stride]; curs = (uint32_t)gmask[seg + idxs]; }
+			Rows nx;
+			bool nvalid;
+			fetch(seg + __builtin_amdgcn_readlane((int)idxs, 0), nx, nvalid);
+			for (int e = 0; e < ne; e++) {
+				const Rows cu = nx;
+				const bool valid = nvalid;
+				const int b = seg + __builtin_amdgcn_readlane((int)idxs, e);
+				const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)curs, e);
+				if (e + 1 < ne) fetch(seg + __builtin_amdgcn_readlane((int)idxs, e + 1), nx, nvalid);
+				uint32_t bw[8];
+				permute_block(cu.r0.x, cu.r0.y, cu.r1.x, cu.r1.y, cu.r2.x, cu.r2.y, cu.r3.x, cu.r3.y, (const LDS(uint32_t) *)otab + (cu.bt >> 24) * 16, bw);
+				uint32_t aw[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) aw[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw[j]);  // lane 0 = block A
+				uint32_t hi_or = 0;
+#pragma unroll
+				for (int j = 0; j < 8; j++) hi_or |= bw[j];
+				const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
+				uint32_t up;
+				if (small) {
+					// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences
+					// are exact: count the NEGATIVE results of B[t] - (A[t] + 65) and A[t+1] - (B[t] + 65).  A is
+					// wave-uniform: its terms are scalar (no carry between the halves below 0x4000); t = 15 has no
+					// successor: 0 - (B + 65) < 0
+					const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
+					uint32_t neg = 0;
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const uint32_t a65 = aw[j] + K65;
+						const uint32_t an = (j < 7) ? ((aw[j] >> 16) | (aw[j + 1] << 16)) : (aw[7] >> 16);
+						neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[j], a65)));
+						neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(an, pk_add(bw[j], K65))));
+					}
+					up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
+				} else {
+					up = 0;
+					int bprev = 0;
+#pragma unroll
+					for (int t = 0; t < 16; t++) {
+						int av = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
+						if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
+						if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
+						up += (bv - av >= 65) ? 1u : 0u;
+						bprev = bv;
+					}
+				}
+				// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
+				const bool fit = valid && (b == 0 ? true : ((up + 1u) < (cur - 2u)));
+				const uint64_t mk = __ballot(fit);
+				if (lane == 0) gmask[b] = mk;
 			}
 		}
-		if (s == nT - 1) {
-			__syncthreads();
-			halo = (*halo_flag != 0);
-			if (halo) load_tile(t0 + nT, r);
-		}
-		// ---- candidate masks of the previous tile (its list was completed before this step's barrier)
-		if (s >= 1) {
-			const int ps = s - 1;
-			LDS(uint8_t) *cs = dlin + (ps % 3) * TILE_BYTES;
-			const uint32_t c0 = lcnt[(ps % 3) * 2], c1 = lcnt[(ps % 3) * 2 + 1];
-			const LDS(uint16_t) *l0 = lst + (ps % 3) * 2 * 128;
-			const int tb = (t0 + ps) * 256;
-			for (uint32_t e = wave; e < c0 + c1; e += 2) {
-				const uint32_t ent = e < c0 ? l0[e] : l0[128 + e - c0];
-				const int i = (int)(ent & 0xFFu);
-				const uint32_t cur = ent >> 8;
-				const int p = i + lane;
-				const bool valid = lane >= 1 && tb + p < NB;
-				const int pk = valid ? p : i;
-				const LDS(uint16_t) *ap = (const LDS(uint16_t) *)(cs + i * 32);
-				const LDS(uint16_t) *bp = (const LDS(uint16_t) *)((pk < 256 ? cs : slot) + (pk & 255) * 32);
-				const uint64_t mk = fit_mask<SGN>(ap, bp, valid, cur, tb + i == 0);
-				if (lane == 0) gmask[tb + i] = mk;
-			}
-		}
+		__syncthreads();  // the list is rebuilt for the next segment
 	}
 }
 
@@ -350,7 +426,7 @@ constexpr int K2_CAP = 4096;                      // difficult-list records kept
 constexpr int K2_ROLE = 0;                        // PIPE_MAX_NB bytes
 constexpr int K2_IDX = PIPE_MAX_NB;               // K2_CAP u32
 constexpr int K2_MASK = K2_IDX + K2_CAP * 4;      // K2_CAP u64
-constexpr int K2_TSUM = K2_MASK + K2_CAP * 8;     // TILE_MAX_TILES/4 = 256 i32 (sum of single sizes + corrections)
+constexpr int K2_TSUM = K2_MASK + K2_CAP * 8;     // 256 i32 (sum of single sizes + corrections per tile)
 constexpr int K2_MISC = K2_TSUM + 256 * 4;
 constexpr int K2_LDS = K2_MISC + 128;
 
@@ -367,8 +443,11 @@ __device__ __forceinline__ uint32_t wg_incl_scan256(uint32_t v, LDS(uint32_t) *s
 	return base + inc;
 }
 
-__global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
+template <bool STAMP>
+__global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t *stamps)
 {
+	Stamps st;
+	stamp_init<STAMP>(st);
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem2[];
 	LDS(uint8_t) *role = (LDS(uint8_t) *)(smem2 + K2_ROLE);
 	LDS(uint32_t) *l_idx = (LDS(uint32_t) *)(smem2 + K2_IDX);
@@ -395,6 +474,7 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 	for (int i = tid; i < NT; i += K2T) tsum[i] = 0;
 	if (tid < 8) misc[tid] = 0;
 	__syncthreads();
+	stamp<STAMP>(st, 0);
 
 	// ---- ordered list of difficult blocks + sum of the single sizes per tile
 	const int n16 = NB / 16;                              // 16 blocks per chunk, 16 chunks per tile
@@ -407,13 +487,13 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
 			cnt += (uint32_t)__popc(w[q] & 0x80808080u);
-			const uint32_t sz = w[q] & 0x7F7F7F7Fu;
-			sum += (sz & 0xFFu) + ((sz >> 8) & 0xFFu) + ((sz >> 16) & 0xFFu) + (sz >> 24);
+			sum = __builtin_amdgcn_udot4(w[q] & 0x7F7F7F7Fu, 0x01010101u, sum, false);
 		}
 		lds_add(&tsum[c >> 4], (int32_t)sum);
 	}
 	uint32_t ndiff;
 	uint32_t pos = wg_incl_scan256(cnt, misc, tid, ndiff) - cnt;
+	stamp<STAMP>(st, 1);
 	if (seg && ndiff) {
 		for (int c = tid * cpl; c < min(n16, (tid + 1) * cpl); c++) {
 			const u32x4 v = *reinterpret_cast<const u32x4 *>(ssz + (size_t)c * 16);
@@ -425,27 +505,54 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 					const int bit = __ffs((int)m) - 1;
 					m &= m - 1;
 					const uint32_t b = (uint32_t)(c * 16 + q * 4 + (bit >> 3));
-					if (pos < K2_CAP) { l_idx[pos] = b; l_mask[pos] = gmask[b]; } else g_idx[pos] = b;
+					if (pos < K2_CAP) l_idx[pos] = b; else g_idx[pos] = b;
 					pos++;
 				}
 			}
 		}
+		__syncthreads();
+		// all masks with independent loads (one round trip)
+		for (uint32_t e = tid; e < min(ndiff, (uint32_t)K2_CAP); e += K2T) l_mask[e] = gmask[l_idx[e]];
 	}
 	__syncthreads();
+	stamp<STAMP>(st, 2);
 
-	// ---- resolve: greedy first fit (cluster.py:79-190), one lane per island of difficult blocks
-	if (seg) {
-		for (uint32_t e0 = tid; e0 < ndiff; e0 += K2T) {
+	// ---- resolve: greedy first fit (cluster.py:79-190).  A block whose mask is empty can neither take a partner nor
+	// change the state of the walk (being taken is decided by its leader), so only the others are walked: fewer, shorter
+	// islands (two of them more than 63 blocks apart cannot influence each other), one lane per island
+	uint32_t nwalk = 0;
+	if (seg && ndiff) {
+		const uint32_t chunk = (ndiff + K2T - 1) / K2T;  // contiguous entries per lane keep the order
+		const uint32_t lo = min(ndiff, tid * chunk), hi = min(ndiff, lo + chunk);
+		uint32_t nz = 0;
+		for (uint32_t e = lo; e < hi; e++) nz += mask_of(e, idx_of(e)) != 0 ? 1u : 0u;
+		uint32_t wpos = wg_incl_scan256(nz, misc, tid, nwalk) - nz;
+		// compaction in place: entry e moves to wpos <= e; every lane reads its own range before anyone writes behind it
+		uint32_t ki[8]; uint64_t km[8];
+		const bool fits = chunk <= 8;
+		if (fits) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const uint32_t e = lo + u; ki[u] = e < hi ? idx_of(e) : 0u; km[u] = e < hi ? mask_of(e, ki[u]) : 0ull; }
+		}
+		__syncthreads();
+		if (fits) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (km[u] != 0) { l_idx[wpos] = ki[u]; l_mask[wpos] = km[u]; wpos++; }
+		} else nwalk = ndiff;  // more than 2048 difficult blocks: walk them all (correct, slower)
+		__syncthreads();
+		for (uint32_t e0 = tid; e0 < nwalk; e0 += K2T) {
 			const uint32_t i0 = idx_of(e0);
 			if (e0 > 0 && i0 - idx_of(e0 - 1) <= 63u) continue;  // not the head of an island
-			uint64_t cw = 0;                                    // blocks at base + bit already consumed as partners
-			uint32_t base = i0, e = e0, i = i0;
+			uint64_t cw = 0;                                    // blocks at i + bit already consumed as partners
+			uint32_t e = e0, i = i0;
+			uint64_t mk = mask_of(e0, i0);
 			for (;;) {
-				const uint32_t sh = i - base;
-				cw = (sh >= 64u) ? 0ull : (cw >> sh);
-				base = i;
+				// the next record is fetched while this one is decided
+				const bool more = e + 1 < nwalk;
+				const uint32_t inext = more ? idx_of(e + 1) : 0u;
+				const uint64_t mnext = more ? mask_of(e + 1, inext) : 0ull;
 				if (!(cw & 1ull)) {
-					const uint64_t avail = mask_of(e, i) & ~cw & ~1ull;
+					const uint64_t avail = mk & ~cw & ~1ull;
 					if (avail) {
 						const int j = __ffsll((long long)avail) - 1;
 						role[i] = (uint8_t)j;
@@ -453,40 +560,56 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 						cw |= 1ull << j;
 					}
 				}
-				if (++e >= ndiff) break;
-				const uint32_t inext = idx_of(e);
-				if (inext - i > 63u) break;
-				i = inext;
+				if (!more || inext - i > 63u) break;
+				cw >>= (inext - i);
+				i = inext; mk = mnext; e++;
 			}
 		}
 	}
 	__syncthreads();
+	stamp<STAMP>(st, 3);
 
 	// ---- meshed pairs: their token bytes (core.py:281-323 along the interleaved order of cluster.py:173-174), and the
 	// blocks that follow a meshed block: their predecessor pixel is the last pixel of the previous GROUP
-	// last pixel written before block b's group (b > 0, b not a partner)
-	auto true_prev = [&](int b) -> int {
+	// traversal position of the last pixel written before block b's group (b > 0, b not a partner)
+	auto true_prev_pos = [&](int b) -> int {
 		int q = b - 1;
 		int rq = role[q];
 		if (rq != 0) {
 			while (rq == ROLE_PARTNER) { q--; rq = role[q]; }
 			if (rq != 0) q += rq;  // a pair ends with its partner's last pixel
 		}
-		return PX(q * 16 + 15);
+		return q * 16 + 15;
 	};
 	uint32_t q7 = 0;
 	if (seg) {
-		for (uint32_t e = tid; e < ndiff; e += K2T) {
+		for (uint32_t e = tid; e < nwalk; e += K2T) {  // every leader has a non-empty mask
 			const int i = (int)idx_of(e);
 			const int r = role[i];
 			if (r == 0 || r == ROLE_PARTNER) continue;
 			const int p = i + r;
 			const uint32_t slot = lds_add(&misc[4], 1u);
 			uint8_t *out = rec + (size_t)slot * PIPE_PAIR_REC;
-			int prev = i > 0 ? true_prev(i) : 0;
+			// every position first, then every pixel: two round trips for the whole pair and its two followers
+			const int bs[2] = {i + 1, p + 1};
+			bool follow[2];
+			int fpos[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				follow[h] = bs[h] < NB && role[bs[h] < NB ? bs[h] : 0] == 0;
+				fpos[h] = follow[h] ? true_prev_pos(bs[h]) : 0;
+			}
+			int prev = i > 0 ? PX(true_prev_pos(i)) : 0;
 			int va[16], vb[16];
 #pragma unroll
 			for (int t = 0; t < 16; t++) { va[t] = PX(i * 16 + t); vb[t] = PX(p * 16 + t); }
+			int ftp[2], fdp[2], fv0[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int b = follow[h] ? bs[h] : 1;
+				ftp[h] = PX(fpos[h]); fdp[h] = PX(b * 16 - 1); fv0[h] = PX(b * 16);
+			}
+			const int sz_i = ssz[i] & 0x7F, sz_p = ssz[p] & 0x7F;
 			int n = 0;
 			out[n++] = (uint8_t)(0x80 | r);  // core.py:290-294
 			auto put = [&](int dlt) {
@@ -499,21 +622,21 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 #pragma unroll
 			for (int t = 0; t < 16; t++) { put(va[t] - prev); put(vb[t] - va[t]); prev = vb[t]; }
 			spec[i] = (slot << 8) | (uint32_t)n;
-			lds_add(&tsum[i >> 8], n - (int)(ssz[i] & 0x7F));
-			lds_add(&tsum[p >> 8], -(int)(ssz[p] & 0x7F));
+			lds_add(&tsum[i >> 8], n - sz_i);
+			lds_add(&tsum[p >> 8], -sz_p);
 			// blocks after the leader and after the partner, if emitted alone
+#pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const int b = (h ? p : i) + 1;
-				if (b >= NB || role[b] != 0) continue;
-				const int tp = true_prev(b), dp = PX(b * 16 - 1), v0 = PX(b * 16);
-				spec[b] = (uint32_t)tp;
-				const int corr = (int)tok_two(v0 - tp) - (int)tok_two(v0 - dp);
-				if (corr) lds_add(&tsum[b >> 8], corr);
+				if (!follow[h]) continue;
+				spec[bs[h]] = (uint32_t)ftp[h];
+				const int corr = (int)tok_two(fv0[h] - ftp[h]) - (int)tok_two(fv0[h] - fdp[h]);
+				if (corr) lds_add(&tsum[bs[h] >> 8], corr);
 			}
 		}
 	}
 	if (q7) lds_or(&misc[5], CCT_ST_Q7);
 	__syncthreads();
+	stamp<STAMP>(st, 4);
 
 	// ---- roles to HBM (K3 and the caller), tile offsets, slice size, statistics
 	uint8_t *groles = a.roles + (size_t)sl * NB;
@@ -538,21 +661,23 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a)
 		a.e.sizes[sl] = cap ? 0u : size;
 		a.e.status[sl] = misc[5] | (cap ? CCT_ST_CAP : 0u);
 		if (a.e.stats) {
-			uint32_t *st = a.e.stats + (size_t)sl * 4;
+			uint32_t *sts = a.e.stats + (size_t)sl * 4;
 			const uint32_t nfull = total - (uint32_t)N - njump;
-			st[0] = (uint32_t)N - nfull; st[1] = nfull; st[2] = njump; st[3] = seg ? ndiff : 0u;
+			sts[0] = (uint32_t)N - nfull; sts[1] = nfull; sts[2] = njump; sts[3] = seg ? ndiff : 0u;
 		}
 	}
+	stamp<STAMP>(st, 5);
+	stamp_store<STAMP>(st, stamps, blockIdx.x * 4 + (tid >> 6));
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------
-constexpr int K3_DLIN = 0;                        // 8192
-constexpr int K3_STG = TILE_BYTES;                // STG_BYTES
-constexpr int K3_TTAB = K3_STG + STG_BYTES;       // 16 entries x 128 bytes (the index arrives as mask-sum << 7)
-constexpr int K3_RTAB = K3_TTAB + 2048;           // 512
-constexpr int K3_OTAB = K3_RTAB + 512;            // 256
-constexpr int K3_PAIR = K3_OTAB + 256;            // PAIR_CAP x 8
-constexpr int K3_MISC = K3_PAIR + PAIR_CAP * 8;   // [0..1] wave totals, [2] pair count, [3] status
+constexpr int K3_STG = 0;                         // STG_BYTES
+constexpr int K3_TTAB = STG_BYTES;                // 16 entries x 128 bytes (the index arrives as mask-sum << 7)
+constexpr int K3_OTAB = K3_TTAB + 2048;           // 256
+constexpr int K3_SZL = K3_OTAB + 256;             // 256 token sizes of the tile's blocks, traversal order
+constexpr int K3_OFFL = K3_SZL + 256;             // 2 x 256 u16: their offsets, one copy per wave
+constexpr int K3_PAIR = K3_OFFL + 1024;           // PAIR_CAP x 8
+constexpr int K3_MISC = K3_PAIR + PAIR_CAP * 8;   // [2] pair count, [3] status
 constexpr int K3_LDS = K3_MISC + 64;
 
 // two-byte masks of the four 4-pixel groups of a block: bit 7 of byte p of m[g] <=> pixel 4g+p takes two bytes
@@ -613,14 +738,17 @@ __device__ __forceinline__ void emit_block(const uint32_t x[8], const uint32_t m
 	}
 }
 
-__global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a)
+template <bool STAMP>
+__global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a, uint64_t *stamps)
 {
+	Stamps st;
+	stamp_init<STAMP>(st);
 	__shared__ __attribute__((aligned(16))) uint8_t smem[K3_LDS];
-	LDS(uint8_t) *dlin = (LDS(uint8_t) *)(smem + K3_DLIN);
 	LDS(uint8_t) *stg = (LDS(uint8_t) *)(smem + K3_STG);
 	LDS(uint8_t) *ttab = (LDS(uint8_t) *)(smem + K3_TTAB);
-	LDS(uint32_t) *rtab = (LDS(uint32_t) *)(smem + K3_RTAB);
 	LDS(uint32_t) *otab = (LDS(uint32_t) *)(smem + K3_OTAB);
+	LDS(uint8_t) *szl = (LDS(uint8_t) *)(smem + K3_SZL);
+	LDS(uint16_t) *offl = (LDS(uint16_t) *)(smem + K3_OFFL);
 	LDS(uint32_t) *pairs = (LDS(uint32_t) *)(smem + K3_PAIR);
 	LDS(uint32_t) *misc = (LDS(uint32_t) *)(smem + K3_MISC);
 
@@ -632,113 +760,111 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a)
 	const int pitch = a.row_pitch;
 	const int to = a.tile_orient[tile];
 
-	// ---- loads first: pixel rows, roles, offsets
+	// ---- loads first: the lane's table entry, pixel rows, then what depends on the entry
+	const u32x4 ent = reinterpret_cast<const u32x4 *>(a.ptab)[to * PW + tid];
 	const int by = tid >> 3, bxp = tid & 7;
-	const uint16_t *p = img + a.tile_org[tile] + (size_t)(by * 4) * pitch + bxp * 8;
+	const uint32_t org = a.tile_org[tile];
+	const uint16_t *p = img + org + (size_t)(by * 4) * pitch + bxp * 8;
 	u32x4 r[4];
 #pragma unroll
 	for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
-	const int b0 = tile * 256 + 2 * tid;  // the lane's two consecutive traversal blocks
-	const uint8_t *roles = a.roles + (size_t)sl * NB;
-	const uint32_t rr = *reinterpret_cast<const uint16_t *>(roles + b0);
-	const uint32_t role0 = rr & 0xFFu, role1 = rr >> 8;
-	const uint32_t rolep = b0 > 0 ? roles[b0 - 1] : 0u;
 	const uint32_t *toff = a.toff + (size_t)sl * (NT + 1);
 	const uint32_t off_t = toff[tile], off_n = toff[tile + 1];
-	const uint32_t *spec = a.spec + (size_t)sl * NB;
-	uint32_t tile_prev = 0;
-	if (tid == 0 && tile > 0) tile_prev = img[a.tile_org[tile - 1] + a.tile_last[a.tile_orient[tile - 1]]];
+	const int kA = (int)(ent.x & 0xFFu), kB = (int)((ent.x >> 16) & 0xFFu);
+	const int bA = tile * 256 + kA, bB = tile * 256 + kB;
+	const uint8_t *roles = a.roles + (size_t)sl * NB;
+	const uint32_t roleA = roles[bA], roleB = roles[bB];
+	const uint32_t rolepA = bA > 0 ? roles[bA - 1] : 0u, rolepB = bB > 0 ? roles[bB - 1] : 0u;
+	const uint32_t porg = tile > 0 ? a.tile_org[tile - 1] + a.tile_last[a.tile_orient[tile - 1]] : 0u;
+	uint32_t pvA = img[ent.y != 0xFFFFFFFFu ? org + ent.y : porg];
+	uint32_t pvB = img[ent.z != 0xFFFFFFFFu ? org + ent.z : porg];
+	if (bA == 0) pvA = 0;  // the slice starts from pixel value 0 (core.py:278)
+	if (bB == 0) pvB = 0;
 	// special blocks: leaders carry their record and size, blocks after a meshed block their predecessor pixel
-	const bool lead0 = role0 >= 1 && role0 <= 63, lead1 = role1 >= 1 && role1 <= 63;
-	const bool succ0 = role0 == 0 && rolep != 0, succ1 = role1 == 0 && role0 != 0;
-	uint32_t sp0 = 0, sp1 = 0;
-	if (lead0 || succ0) sp0 = spec[b0];
-	if (lead1 || succ1) sp1 = spec[b0 + 1];
+	const uint32_t *spec = a.spec + (size_t)sl * NB;
+	const bool leadA = roleA >= 1 && roleA <= 63, leadB = roleB >= 1 && roleB <= 63;
+	const bool succA = roleA == 0 && rolepA != 0, succB = roleB == 0 && rolepB != 0;
+	uint32_t spA = 0, spB = 0;
+	if (leadA || succA) spA = spec[bA];
+	if (leadB || succB) spB = spec[bB];
 
 	// ---- tables and the zeroed payload image
-	rtab[tid] = reinterpret_cast<const uint32_t *>(a.rtab)[to * 128 + tid];
 	if (tid < 64) otab[tid] = a.otab[tid];
 	if (tid < 16) *(LDS(u32x4) *)(ttab + tid * 128) = reinterpret_cast<const u32x4 *>(a.ttab)[tid];
 	for (int i = tid; i < STG_BYTES / 16; i += PW) *(LDS(u32x4) *)(stg + i * 16) = (u32x4){0, 0, 0, 0};
 	if (tid < 4) misc[tid] = 0;
+	stamp<STAMP>(st, 0);
 	__syncthreads();
+	stamp<STAMP>(st, 1);
 
-	// ---- traversal order through LDS
-	{
-		const uint32_t e2 = rtab[tid];
-		const int kA = (int)(e2 & 0xFFu), kB = (int)((e2 >> 16) & 0xFFu);
-		uint32_t dA[8], dB[8];
-		permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((e2 >> 8) & 3u) * 16, dA);
-		permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((e2 >> 24) & 3u) * 16, dB);
-		*(LDS(u32x4) *)(dlin + kA * 32) = (u32x4){dA[0], dA[1], dA[2], dA[3]};
-		*(LDS(u32x4) *)(dlin + kA * 32 + 16) = (u32x4){dA[4], dA[5], dA[6], dA[7]};
-		*(LDS(u32x4) *)(dlin + kB * 32) = (u32x4){dB[0], dB[1], dB[2], dB[3]};
-		*(LDS(u32x4) *)(dlin + kB * 32 + 16) = (u32x4){dB[4], dB[5], dB[6], dB[7]};
-	}
-	__syncthreads();
-	uint32_t d[16];
-	{
-		const LDS(u32x4) *src = (const LDS(u32x4) *)(dlin + tid * 64);
-		const u32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-		d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
-		d[8] = v2.x; d[9] = v2.y; d[10] = v2.z; d[11] = v2.w; d[12] = v3.x; d[13] = v3.y; d[14] = v3.z; d[15] = v3.w;
-	}
-	uint32_t pv0 = tid > 0 ? (uint32_t) * (const LDS(uint16_t) *)(dlin + tid * 64 - 2) : tile_prev;
-	if (succ0) pv0 = sp0;
-	uint32_t pv1 = d[7] >> 16;
-	if (succ1) pv1 = sp1;
-
-	// ---- token sizes
-	uint32_t x[16], m[8];
-	deltas16(d, pv0, x);
-	deltas16(d + 8, pv1, x + 8);
-	uint32_t orall = 0;
+	// ---- traversal order inside the lane's two blocks, deltas, token sizes
+	uint32_t dA[8], dB[8], xA[8], xB[8], mA[4], mB[4];
+	permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((ent.x >> 8) & 3u) * 16, dA);
+	permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((ent.x >> 24) & 3u) * 16, dB);
+	if (succA) pvA = spA;
+	if (succB) pvB = spB;
+	deltas16(dA, pvA, xA);
+	deltas16(dB, pvB, xB);
+	uint32_t orall = pvA | pvB;
 #pragma unroll
-	for (int j = 0; j < 16; j++) orall |= d[j];
-	orall |= pv0 | pv1;
+	for (int j = 0; j < 8; j++) orall |= dA[j] | dB[j];
 	bool q7 = false;
-	uint32_t n20, n21;
+	uint32_t n2A, n2B;
 	if (!__any((orall & 0xC000C000u) != 0)) {
-		n20 = group_masks(x, m);
-		n21 = group_masks(x + 8, m + 4);
+		n2A = group_masks(xA, mA);
+		n2B = group_masks(xB, mB);
 		if (__any((orall & 0xF800F800u) != 0)) {  // a delta outside [-2047, 2048] needs a pixel >= 2048
 			const uint32_t K2048 = 0x08000800u, K2047 = 0x07FF07FFu;
 			uint32_t bad0 = 0, bad1 = 0;
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				bad0 |= pk_sub(K2048, x[j]) | pk_add(x[j], K2047);
-				bad1 |= pk_sub(K2048, x[8 + j]) | pk_add(x[8 + j], K2047);
+				bad0 |= pk_sub(K2048, xA[j]) | pk_add(xA[j], K2047);
+				bad1 |= pk_sub(K2048, xB[j]) | pk_add(xB[j], K2047);
 			}
-			q7 = (role0 == 0 && (bad0 & 0x80008000u)) || (role1 == 0 && (bad1 & 0x80008000u));
+			q7 = (roleA == 0 && (bad0 & 0x80008000u)) || (roleB == 0 && (bad1 & 0x80008000u));
 		}
 	} else {
 		bool qa = false, qb = false;
-		n20 = group_masks_wide(d, pv0, m, qa);
-		n21 = group_masks_wide(d + 8, pv1, m + 4, qb);
-		q7 = (role0 == 0 && qa) || (role1 == 0 && qb);
+		n2A = group_masks_wide(dA, pvA, mA, qa);
+		n2B = group_masks_wide(dB, pvB, mB, qb);
+		q7 = (roleA == 0 && qa) || (roleB == 0 && qb);
 	}
-	const uint32_t sz0 = role0 == 0 ? 16u + n20 : (lead0 ? (sp0 & 0xFFu) : 0u);
-	const uint32_t sz1 = role1 == 0 ? 16u + n21 : (lead1 ? (sp1 & 0xFFu) : 0u);
-	const uint32_t inc = wave_incl_scan(sz0 + sz1);
-	if (lane == 63) misc[wave] = inc;
+	const uint32_t szA = roleA == 0 ? 16u + n2A : (leadA ? (spA & 0xFFu) : 0u);
+	const uint32_t szB = roleB == 0 ? 16u + n2B : (leadB ? (spB & 0xFFu) : 0u);
+	szl[kA] = (uint8_t)szA;
+	szl[kB] = (uint8_t)szB;
+	stamp<STAMP>(st, 2);
 	__syncthreads();
+	stamp<STAMP>(st, 3);
+	// ---- offsets: every wave scans the 256 sizes for itself (no second barrier), four blocks per lane
+	uint32_t tot;
+	{
+		const uint32_t v = *(const LDS(uint32_t) *)(szl + lane * 4);
+		const uint32_t s0 = v & 0xFFu, s1 = (v >> 8) & 0xFFu, s2 = (v >> 16) & 0xFFu, s3 = v >> 24;
+		const uint32_t sum4 = s0 + s1 + s2 + s3;
+		const uint32_t inc = wave_incl_scan(sum4);
+		tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+		const uint32_t e0 = inc - sum4, e1 = e0 + s0, e2 = e1 + s1, e3 = e2 + s2;
+		typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+		*(LDS(u32x2) *)(offl + wave * 256 + lane * 4) = (u32x2){e0 | (e1 << 16), e2 | (e3 << 16)};
+	}
 	const uint32_t head = off_t & 15u;
-	const uint32_t tot = misc[0] + misc[1];
-	uint32_t o0 = head + (wave ? misc[0] : 0u) + inc - (sz0 + sz1);
-	const uint32_t o1 = o0 + sz0;
+	const uint32_t oA = head + offl[wave * 256 + kA], oB = head + offl[wave * 256 + kB];
+	stamp<STAMP>(st, 4);
 
 	// ---- tokens into the payload image
-	if (role0 == 0) emit_block(x, m, o0, stg, ttab);
-	if (role1 == 0) emit_block(x + 8, m + 4, o1, stg, ttab);
-	if (lead0) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = o0; pairs[2 * e + 1] = sp0; }
-	if (lead1) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = o1; pairs[2 * e + 1] = sp1; }
-	uint32_t st = q7 ? CCT_ST_Q7 : 0u;
-	if (tid == 0 && tot != off_n - off_t) st |= CCT_ST_INTERNAL;
-	if (st) lds_or(&misc[3], st);
+	if (roleA == 0) emit_block(xA, mA, oA, stg, ttab);
+	if (roleB == 0) emit_block(xB, mB, oB, stg, ttab);
+	if (leadA) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = oA; pairs[2 * e + 1] = spA; }
+	if (leadB) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = oB; pairs[2 * e + 1] = spB; }
+	uint32_t stat = q7 ? CCT_ST_Q7 : 0u;
+	if (tid == 0 && tot != off_n - off_t) stat |= CCT_ST_INTERNAL;
+	if (stat) lds_or(&misc[3], stat);
+	stamp<STAMP>(st, 5);
 	__syncthreads();
 	// ---- meshed pairs: K2 left their bytes in HBM records
-	{
-		const uint32_t npair = misc[2];
+	const uint32_t npair = misc[2];
+	if (npair) {
 		const uint8_t *rec = a.pairrec + (size_t)sl * (NB / 2) * PIPE_PAIR_REC;
 		for (uint32_t e = wave; e < npair; e += 2) {
 			const uint32_t o = pairs[2 * e], sp = pairs[2 * e + 1];
@@ -746,9 +872,10 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a)
 			const uint8_t *src = rec + (size_t)(sp >> 8) * PIPE_PAIR_REC;
 			for (uint32_t j = lane; j < n; j += 64) stg[o + j] = src[j];
 		}
-		if (tile == NT - 1 && a.e.eof >= 0 && tid == 0) stg[head + tot] = (uint8_t)a.e.eof;  // core.py:329-330
 	}
-	__syncthreads();
+	if (tile == NT - 1 && a.e.eof >= 0 && tid == 0) stg[head + tot] = (uint8_t)a.e.eof;  // core.py:329-330
+	if (npair || tile == NT - 1) __syncthreads();
+	stamp<STAMP>(st, 6);
 	// ---- flush: whole 16-byte chunks with one store, the two ends shared with the neighbouring tiles byte by byte
 	{
 		const bool last = tile == NT - 1;
@@ -769,31 +896,97 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a)
 		}
 		if (tid == 0 && misc[3]) atomicOr(a.e.status + sl, misc[3] | (room ? 0u : CCT_ST_CAP));
 	}
+	stamp<STAMP>(st, 7);
+	stamp_store<STAMP>(st, stamps, blockIdx.x * 2 + wave);
 }
 
 }  // namespace
 
-hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s)
+// diagnostic build: CCT_PIPE_STAMPS=1 runs the stamped instantiations once and prints the mean cycles per phase
+static void report_stamps(const char *name, const uint64_t *d_buf, size_t nslots, const char *const *phase)
+{
+	std::vector<uint64_t> h(nslots * 8);
+	if (hipMemcpy(h.data(), d_buf, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+	double sum[8] = {0};
+	for (size_t i = 0; i < nslots; i++) for (int p = 0; p < 8; p++) sum[p] += (double)h[i * 8 + p];
+	double all = 0;
+	for (int p = 0; p < 8; p++) all += sum[p];
+	fprintf(stderr, "[stamps] %s: %.0f shader cycles per wave:", name, all / nslots);
+	for (int p = 0; p < 8; p++) if (phase[p]) fprintf(stderr, "  %s %.0f", phase[p], sum[p] / nslots);
+	fprintf(stderr, "\n");
+}
+
+hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const PipeTune *tune)
 {
 	const int NT = pa.n_tiles;
-	const int tpw = NT >= 16 ? 4 : (NT >= 4 ? 2 : 1);  // tiles per K1 workgroup
+	int tpw = NT >= 64 ? 16 : (NT >= 16 ? 4 : 1);  // tiles per K1a workgroup
+	if (tune && tune->tpw > 0) tpw = std::min(tune->tpw, NT);
 	const int wps = (NT + tpw - 1) / tpw;
 	const bool sg = (pa.e.flags & CCT_FLAG_SIGNED_SEG) != 0;
-	if (sg) hipLaunchKernelGGL(pipe_analyse_kernel<true>, dim3(n * wps), dim3(PW), 0, s, pa, tpw);
-	else hipLaunchKernelGGL(pipe_analyse_kernel<false>, dim3(n * wps), dim3(PW), 0, s, pa, tpw);
+	const bool seg = (pa.e.flags & CCT_FLAG_SEGMENTATION) != 0;
+	static const bool stamps_on = getenv("CCT_PIPE_STAMPS") != nullptr;
+	uint64_t *d_st = nullptr;
+	const size_t slots1 = (size_t)n * wps * 2, slots3 = (size_t)n * NT * 2;
+	if (stamps_on) {
+		if (hipMalloc(&d_st, std::max(std::max(slots1, slots3), (size_t)n * 4) * 64) != hipSuccess) return hipErrorOutOfMemory;
+		(void)hipMemset(d_st, 0, std::max(std::max(slots1, slots3), (size_t)n * 4) * 64);
+	}
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	const bool timing = tune && tune->times_us;
+	if (timing) for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return hipErrorUnknown;
+	if (timing) (void)hipEventRecord(ev[0], s);
+	if (stamps_on) {
+		if (sg) hipLaunchKernelGGL((pipe_analyse_kernel<true, true>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, d_st);
+		else hipLaunchKernelGGL((pipe_analyse_kernel<false, true>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, d_st);
+		(void)hipStreamSynchronize(s);
+		static const char *const ph1[8] = {"setup", "perm+prefetch", "analysis", "prev-px", nullptr, nullptr, nullptr, nullptr};
+		report_stamps("K1a analyse", d_st, slots1, ph1);
+	} else if (sg) hipLaunchKernelGGL((pipe_analyse_kernel<true, false>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, (uint64_t *)nullptr);
+	else hipLaunchKernelGGL((pipe_analyse_kernel<false, false>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, (uint64_t *)nullptr);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
+	if (timing) (void)hipEventRecord(ev[1], s);
+	if (seg) {
+		if (sg) hipLaunchKernelGGL(pipe_masks_kernel<true>, dim3(n * MQ), dim3(64 * MW), 0, s, pa);
+		else hipLaunchKernelGGL(pipe_masks_kernel<false>, dim3(n * MQ), dim3(64 * MW), 0, s, pa);
+		e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	if (timing) (void)hipEventRecord(ev[2], s);
 	static bool attr_set = false;
 	if (!attr_set) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void *>(pipe_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS);
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(pipe_resolve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS);
+		if (e != hipSuccess) return e;
+		e = hipFuncSetAttribute(reinterpret_cast<const void *>(pipe_resolve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(pipe_resolve_kernel, dim3(n), dim3(K2T), K2_LDS, s, pa);
+	if (stamps_on) {
+		(void)hipMemsetAsync(d_st, 0, (size_t)n * 4 * 64, s);
+		hipLaunchKernelGGL(pipe_resolve_kernel<true>, dim3(n), dim3(K2T), K2_LDS, s, pa, d_st);
+		(void)hipStreamSynchronize(s);
+		static const char *const ph2[8] = {"init", "count+scan", "list+masks", "resolve", "pairs", "roles+offsets", nullptr, nullptr};
+		report_stamps("K2 resolve", d_st, (size_t)n * 4, ph2);
+	} else hipLaunchKernelGGL(pipe_resolve_kernel<false>, dim3(n), dim3(K2T), K2_LDS, s, pa, (uint64_t *)nullptr);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(pipe_pack_kernel, dim3(n * NT), dim3(PW), 0, s, pa);
-	return hipGetLastError();
+	if (timing) (void)hipEventRecord(ev[3], s);
+	if (stamps_on) {
+		(void)hipMemsetAsync(d_st, 0, slots3 * 64, s);
+		hipLaunchKernelGGL(pipe_pack_kernel<true>, dim3(n * NT), dim3(PW), 0, s, pa, d_st);
+		(void)hipStreamSynchronize(s);
+		static const char *const ph3[8] = {"loads+tables", "sync", "perm+sizes", "sync", "scan+offsets", "emit", "sync+pairs+sync", "flush"};
+		report_stamps("K3 pack", d_st, slots3, ph3);
+		(void)hipFree(d_st);
+	} else hipLaunchKernelGGL(pipe_pack_kernel<false>, dim3(n * NT), dim3(PW), 0, s, pa, (uint64_t *)nullptr);
+	e = hipGetLastError();
+	if (timing) {
+		(void)hipEventRecord(ev[4], s);
+		(void)hipEventSynchronize(ev[4]);
+		for (int i = 0; i < 4; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); tune->times_us[i] = ms * 1e3f; }
+		for (auto &x : ev) (void)hipEventDestroy(x);
+	}
+	return e;
 }
 
 }  // namespace cct
