@@ -112,7 +112,7 @@ struct Context {
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
-	DevBuf e_toff, e_pairrec, e_spill;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
+	DevBuf e_toff, e_pairrec, e_spill, e_dlist, e_dcount;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	// decode workspaces
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	DevBuf h_stage;  // pinned host staging (payloads)
@@ -507,6 +507,8 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 		if ((rc = g_ctx.e_toff.ensure((size_t)n * (NT + 1) * 4))) return rc;
 		if ((rc = g_ctx.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
 		if ((rc = g_ctx.e_spill.ensure(per * 4))) return rc;
+		if ((rc = g_ctx.e_dlist.ensure(per * 4))) return rc;
+		if ((rc = g_ctx.e_dcount.ensure((size_t)n * 4))) return rc;
 		PipeArgs pa{};
 		pa.e = a;
 		pa.tile_org = tb->d_org; pa.tile_orient = tb->d_orient; pa.ptab = tb->d_ptab; pa.btab = tb->d_btab; pa.otab = tb->d_otab;
@@ -515,6 +517,7 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 		pa.ssz = (uint8_t *)g_ctx.e_lcur.p; pa.mask = (uint64_t *)g_ctx.e_lmask.p; pa.roles = (uint8_t *)g_ctx.e_role.p;
 		pa.spec = (uint32_t *)g_ctx.e_lidx.p; pa.toff = (uint32_t *)g_ctx.e_toff.p; pa.pairrec = (uint8_t *)g_ctx.e_pairrec.p;
 		pa.spill_idx = (uint32_t *)g_ctx.e_spill.p;
+		pa.dlist = (uint32_t *)g_ctx.e_dlist.p; pa.dcount = (uint32_t *)g_ctx.e_dcount.p;
 		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
 		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream, &tune));
 		g_ctx.last_path = 1;

@@ -67,6 +67,8 @@ struct PipeArgs {
 	int n_orient, n_tiles, row_pitch;
 	uint8_t *ssz;                // n * NB: token bytes of every block emitted alone after its traversal predecessor | 0x80 if difficult
 	uint64_t *mask;              // n * NB: candidate fit masks, valid for difficult blocks
+	uint32_t *dlist;             // n * NB: difficult blocks of a slice in any order: block | cur << 24 (work list of the mask kernel)
+	uint32_t *dcount;            // n: entries of dlist
 	uint8_t *roles;              // n * NB: the block partition
 	uint32_t *spec;              // n * NB: leaders: pair record << 8 | group bytes; blocks after a meshed block: predecessor pixel
 	uint32_t *toff;              // n * (n_tiles + 1): payload offset of every tile's first token, then the token total

@@ -40,17 +40,14 @@ constexpr int STG_BYTES = 10496;    // payload bytes of one tile: 15 (alignment)
 constexpr int PAIR_CAP = 256;       // leaders per tile
 
 // ---- packed 16-bit arithmetic (two pixels per instruction) --------------------------------------------
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)  // v_pk_sub_i16; operands may be scalar registers
 {
-	uint32_t r;
-	asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-	return r;
+	return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
 }
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)  // v_pk_add_u16
 {
-	uint32_t r;
-	asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-	return r;
+	return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
 }
 __device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b)
 {
@@ -95,12 +92,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 // ---- diagnostic build only (CCT_PIPE_STAMPS=1): cycles per phase, summed per wave, written to a buffer of their own
 struct Stamps {
 	uint64_t acc[8];
-	uint64_t last;
+	uint64_t last, rt0;
 };
 template <bool ON>
 __device__ __forceinline__ void stamp_init(Stamps &st)
 {
-	if (ON) { for (int i = 0; i < 8; i++) st.acc[i] = 0; st.last = __builtin_amdgcn_s_memtime(); }
+	if (ON) { for (int i = 0; i < 8; i++) st.acc[i] = 0; st.rt0 = __builtin_amdgcn_s_memrealtime(); st.last = __builtin_amdgcn_s_memtime(); }
 }
 template <bool ON>
 __device__ __forceinline__ void stamp(Stamps &st, int phase)
@@ -116,8 +113,13 @@ __device__ __forceinline__ void stamp(Stamps &st, int phase)
 template <bool ON>
 __device__ __forceinline__ void stamp_store(const Stamps &st, uint64_t *buf, int slot)
 {
-	if (ON && (threadIdx.x & 63) == 0 && buf)
-		for (int i = 0; i < 8; i++) buf[(size_t)slot * 8 + i] = st.acc[i];
+	if (ON && (threadIdx.x & 63) == 0 && buf) {
+		uint64_t all = 0;
+		for (int i = 0; i < 7; i++) { buf[(size_t)slot * 8 + i] = st.acc[i]; all += st.acc[i]; }
+		// slot 7: shader cycles per 100 MHz tick, x 1000 (the clock the wave ran at, in units of 100 kHz)
+		const uint64_t rt = __builtin_amdgcn_s_memrealtime() - st.rt0;
+		buf[(size_t)slot * 8 + 7] = rt ? (all + st.acc[7]) * 1000 / rt : 0;
+	}
 }
 
 // ---- front end shared by K1 and K3 ---------------------------------------------------------------------
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 	Stamps st;
 	stamp_init<STAMP>(st);
 	__shared__ __attribute__((aligned(16))) uint32_t otab[64];
-	const int tid = threadIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
 	const int wps = (NT + tpw - 1) / tpw;
@@ -212,7 +214,6 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 	const bool seg = (a.e.flags & CCT_FLAG_SEGMENTATION) != 0;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	uint8_t *ssz = a.ssz + (size_t)sl * NB;
-	uint64_t *gmask = a.mask + (size_t)sl * NB;
 	const int pitch = a.row_pitch;
 	const u32x4 *ptab = reinterpret_cast<const u32x4 *>(a.ptab);
 
@@ -268,7 +269,16 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 			const bool difficult = seg && chg >= 8u;                      // cluster.py:58
 			const int b = tile * 256 + k;
 			ssz[b] = (uint8_t)((16u + n2) | (difficult ? 0x80u : 0u));
-			if (difficult) gmask[b] = (uint64_t)(chg + enter);            // cluster.py:110; K1b replaces it with the mask
+			// difficult blocks go to the slice's work list of the mask kernel (any order), one atomic per wave
+			const uint64_t bal = __ballot(difficult);
+			if (bal) {
+				uint32_t base = 0;
+				if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(a.dcount + sl, (uint32_t)__popcll(bal));
+				base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__ffsll((long long)bal) - 1);
+				if (difficult) {
+					a.dlist[(size_t)sl * NB + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)b | (chg + enter) << 24;  // cluster.py:110
+				}
+			}
 		}
 		stamp<STAMP>(st, 2);
 		if (s + 1 < nT) load_prev(tile + 1, ent, pvA, pvB);
@@ -278,40 +288,43 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 }
 
 // ---- K1b --------------------------------------------------------------------------------------------------
-// MQ workgroups of MW waves per slice.  Every workgroup lists the slice's difficult blocks from the K1a bytes (ordered,
-// in LDS) and its waves take them round-robin, so that the mask work is spread evenly whatever tiles it sits in.  For a
-// difficult block i lane j fetches block i + j (four 8-byte row segments, L2 hits: K1a has just streamed them), puts it
-// in traversal order and counts the positive jumps of the interleaved order A0 B0 A1 B1 ... (cluster.py:131-153); lane 0
-// holds block A itself, whose terms go to SGPRs.  The fetch of the next entry is in flight while this one is evaluated.
-constexpr int MW = 8, MQ = 4;          // waves per workgroup, workgroups per slice
-constexpr int MSEG = 16384;            // blocks listed per pass (the list holds 16-bit indices)
-constexpr int K1B_LIST = 0;            // MSEG u16
-constexpr int K1B_BTAB = MSEG * 2;     // TILE_MAX_ORIENT x 256 u32
+// MQ workgroups of MW waves per slice take the slice's difficult blocks (listed by K1a, any order) round-robin, so that
+// the mask work is spread evenly whatever tiles it sits in.  For a difficult block i lane j fetches block i + j (four
+// 8-byte row segments, cache hits: K1a has just streamed them), puts it in traversal order and counts the positive
+// jumps of the interleaved order A0 B0 A1 B1 ... (cluster.py:131-153); lane 0 holds block A itself, whose terms go to
+// SGPRs.  The fetch of the next entry is in flight while this one is evaluated.
+constexpr int MW = 4, MQ = 8;          // waves per workgroup, workgroups per slice
+constexpr int K1B_BTAB = 0;            // TILE_MAX_ORIENT x 256 u32
 constexpr int K1B_TILE = K1B_BTAB + TILE_MAX_ORIENT * 1024;  // 256 u32: tile origin | orientation << 28
 constexpr int K1B_OTAB = K1B_TILE + 1024;
-constexpr int K1B_MISC = K1B_OTAB + 256;
-constexpr int K1B_LDS = K1B_MISC + 64;
+constexpr int K1B_LDS = K1B_OTAB + 256;
 
-template <bool SGN>
-__global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a)
+template <bool SGN, bool STAMP>
+__global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a, uint64_t *stamps)
 {
+	Stamps st;
+	stamp_init<STAMP>(st);
 	__shared__ __attribute__((aligned(16))) uint8_t smem[K1B_LDS];
-	LDS(uint16_t) *lst = (LDS(uint16_t) *)(smem + K1B_LIST);
 	LDS(uint32_t) *btab = (LDS(uint32_t) *)(smem + K1B_BTAB);
 	LDS(uint32_t) *ltile = (LDS(uint32_t) *)(smem + K1B_TILE);
 	LDS(uint32_t) *otab = (LDS(uint32_t) *)(smem + K1B_OTAB);
-	LDS(uint32_t) *misc = (LDS(uint32_t) *)(smem + K1B_MISC);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
 	const int sl = blockIdx.x / MQ, q = blockIdx.x % MQ;
-	const uint8_t *ssz = a.ssz + (size_t)sl * NB;
+	const int total = (int)a.dcount[sl];
+	const int first = q * MW + wave, stride = MQ * MW;
+	if (q * MW >= total) return;  // nothing for this workgroup (uniform)
+	const uint32_t *dlist = a.dlist + (size_t)sl * NB;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	uint64_t *gmask = a.mask + (size_t)sl * NB;
 	const int pitch = a.row_pitch;
 	for (int i = tid; i < a.n_orient * 256; i += 64 * MW) btab[i] = a.btab[i];
 	for (int i = tid; i < NT; i += 64 * MW) ltile[i] = a.tile_org[i] | (uint32_t)a.tile_orient[i] << 28;
 	if (tid < 64) otab[tid] = a.otab[tid];
+	stamp<STAMP>(st, 0);
+	__syncthreads();
+	stamp<STAMP>(st, 1);
 
 	struct Rows { uint2 r0, r1, r2, r3; uint32_t bt; };
 	// rows of candidate block (b + lane) of the slice; lanes without a candidate re-read block b
@@ -327,97 +340,68 @@ __global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a)
 		o.r3 = *reinterpret_cast<const uint2 *>(p + 3 * (size_t)pitch);
 	};
 
-	for (int seg = 0; seg < NB; seg += MSEG) {
-		const int nseg = min(MSEG, NB - seg);
-		// ---- ordered list of the segment's difficult blocks: 32 bytes per lane
-		const int per = max(1, nseg / (64 * MW));  // bytes per lane: 32 at 16384 blocks, 8 at 4096, 2 at 1024, 1 at 512
-		uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		if (per >= 32) {
-			const u32x4 v0 = *reinterpret_cast<const u32x4 *>(ssz + seg + tid * 32), v1 = *reinterpret_cast<const u32x4 *>(ssz + seg + tid * 32 + 16);
-			w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
-		} else if (per >= 8) {
-			const uint2 v = *reinterpret_cast<const uint2 *>(ssz + seg + tid * 8);
-			w[0] = v.x; w[1] = v.y;
-		} else if (per >= 2) {
-			w[0] = *reinterpret_cast<const uint16_t *>(ssz + seg + tid * 2);
-		} else if (tid < nseg) {
-			w[0] = ssz[seg + tid];
-		}
-		uint32_t cnt = 0;
+	// ---- this wave's entries: first + k * stride, 64 of them listed per round with one load
+	for (int e0 = first; e0 < total; e0 += 64 * stride) {
+		const int ne = min(64, (total - e0 + stride - 1) / stride);
+		uint32_t ents = 0;
+		if (lane < ne) ents = dlist[e0 + lane * stride];
+		Rows nx;
+		bool nvalid;
+		fetch((int)(__builtin_amdgcn_readlane((int)ents, 0) & 0xFFFFFF), nx, nvalid);
+		stamp<STAMP>(st, 2);
+		for (int e = 0; e < ne; e++) {
+			const Rows cu = nx;
+			const bool valid = nvalid;
+			const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)ents, e);
+			const int b = (int)(ent & 0xFFFFFFu);
+			const uint32_t cur = ent >> 24;
+			if (e + 1 < ne) fetch((int)(__builtin_amdgcn_readlane((int)ents, e + 1) & 0xFFFFFF), nx, nvalid);
+			uint32_t bw[8];
+			permute_block(cu.r0.x, cu.r0.y, cu.r1.x, cu.r1.y, cu.r2.x, cu.r2.y, cu.r3.x, cu.r3.y, (const LDS(uint32_t) *)otab + (cu.bt >> 24) * 16, bw);
+			uint32_t aw[8];
 #pragma unroll
-		for (int j = 0; j < 8; j++) { w[j] &= 0x80808080u; cnt += (uint32_t)__popc(w[j]); }
-		const uint32_t inc = wave_incl_scan(cnt);
-		if (lane == 63) misc[wave] = inc;
-		__syncthreads();
-		uint32_t pos = inc - cnt, total = 0;
+			for (int j = 0; j < 8; j++) aw[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw[j]);  // lane 0 = block A
+			uint32_t hi_or = 0;
 #pragma unroll
-		for (int v = 0; v < MW; v++) { const uint32_t t = misc[v]; if (v < wave) pos += t; total += t; }
+			for (int j = 0; j < 8; j++) hi_or |= bw[j];
+			const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
+			uint32_t up;
+			if (small) {
+				// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences
+				// are exact: count the NEGATIVE results of B[t] - (A[t] + 65) and A[t+1] - (B[t] + 65).  A is
+				// wave-uniform: its terms are scalar (no carry between the halves below 0x4000); t = 15 has no
+				// successor: 0 - (B + 65) < 0
+				const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
+				uint32_t neg = 0;
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			uint32_t m = w[j];
-			while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1; lst[pos++] = (uint16_t)(tid * per + j * 4 + (bit >> 3)); }
-		}
-		__syncthreads();
-		// ---- this wave's entries: first + k * stride
-		const int first = q * MW + wave, stride = MQ * MW;
-		for (int e0 = first; e0 < (int)total; e0 += 64 * stride) {
-			const int ne = min(64, ((int)total - e0 + stride - 1) / stride);
-			uint32_t idxs = 0, curs = 0;
-			if (lane < ne) { idxs = lst[e0 + lane * stride]; curs = (uint32_t)gmask[seg + idxs]; }
-			Rows nx;
-			bool nvalid;
-			fetch(seg + __builtin_amdgcn_readlane((int)idxs, 0), nx, nvalid);
-			for (int e = 0; e < ne; e++) {
-				const Rows cu = nx;
-				const bool valid = nvalid;
-				const int b = seg + __builtin_amdgcn_readlane((int)idxs, e);
-				const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)curs, e);
-				if (e + 1 < ne) fetch(seg + __builtin_amdgcn_readlane((int)idxs, e + 1), nx, nvalid);
-				uint32_t bw[8];
-				permute_block(cu.r0.x, cu.r0.y, cu.r1.x, cu.r1.y, cu.r2.x, cu.r2.y, cu.r3.x, cu.r3.y, (const LDS(uint32_t) *)otab + (cu.bt >> 24) * 16, bw);
-				uint32_t aw[8];
-#pragma unroll
-				for (int j = 0; j < 8; j++) aw[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw[j]);  // lane 0 = block A
-				uint32_t hi_or = 0;
-#pragma unroll
-				for (int j = 0; j < 8; j++) hi_or |= bw[j];
-				const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
-				uint32_t up;
-				if (small) {
-					// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences
-					// are exact: count the NEGATIVE results of B[t] - (A[t] + 65) and A[t+1] - (B[t] + 65).  A is
-					// wave-uniform: its terms are scalar (no carry between the halves below 0x4000); t = 15 has no
-					// successor: 0 - (B + 65) < 0
-					const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
-					uint32_t neg = 0;
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						const uint32_t a65 = aw[j] + K65;
-						const uint32_t an = (j < 7) ? ((aw[j] >> 16) | (aw[j + 1] << 16)) : (aw[7] >> 16);
-						neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[j], a65)));
-						neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(an, pk_add(bw[j], K65))));
-					}
-					up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
-				} else {
-					up = 0;
-					int bprev = 0;
-#pragma unroll
-					for (int t = 0; t < 16; t++) {
-						int av = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
-						if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
-						if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
-						up += (bv - av >= 65) ? 1u : 0u;
-						bprev = bv;
-					}
+				for (int j = 0; j < 8; j++) {
+					const uint32_t a65 = aw[j] + K65;
+					const uint32_t an = (j < 7) ? ((aw[j] >> 16) | (aw[j + 1] << 16)) : (aw[7] >> 16);
+					neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[j], a65)));
+					neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(an, pk_add(bw[j], K65))));
 				}
-				// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
-				const bool fit = valid && (b == 0 ? true : ((up + 1u) < (cur - 2u)));
-				const uint64_t mk = __ballot(fit);
-				if (lane == 0) gmask[b] = mk;
+				up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
+			} else {
+				up = 0;
+				int bprev = 0;
+#pragma unroll
+				for (int t = 0; t < 16; t++) {
+					int av = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
+					if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
+					if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
+					up += (bv - av >= 65) ? 1u : 0u;
+					bprev = bv;
+				}
 			}
+			// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
+			const bool fit = valid && (b == 0 ? true : ((up + 1u) < (cur - 2u)));
+			const uint64_t mk = __ballot(fit);
+			if (lane == 0) gmask[b] = mk;
 		}
-		__syncthreads();  // the list is rebuilt for the next segment
+		stamp<STAMP>(st, 3);
 	}
+	if (STAMP) { st.acc[5] = st.rt0; st.acc[6] = __builtin_amdgcn_s_memrealtime(); }  // timeline instead of phases 5, 6
+	stamp_store<STAMP>(st, stamps, blockIdx.x * MW + wave);
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------
@@ -896,7 +880,7 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a, uint64_t *sta
 		}
 		if (tid == 0 && misc[3]) atomicOr(a.e.status + sl, misc[3] | (room ? 0u : CCT_ST_CAP));
 	}
-	stamp<STAMP>(st, 7);
+	stamp<STAMP>(st, 6);
 	stamp_store<STAMP>(st, stamps, blockIdx.x * 2 + wave);
 }
 
@@ -910,9 +894,9 @@ static void report_stamps(const char *name, const uint64_t *d_buf, size_t nslots
 	double sum[8] = {0};
 	for (size_t i = 0; i < nslots; i++) for (int p = 0; p < 8; p++) sum[p] += (double)h[i * 8 + p];
 	double all = 0;
-	for (int p = 0; p < 8; p++) all += sum[p];
-	fprintf(stderr, "[stamps] %s: %.0f shader cycles per wave:", name, all / nslots);
-	for (int p = 0; p < 8; p++) if (phase[p]) fprintf(stderr, "  %s %.0f", phase[p], sum[p] / nslots);
+	for (int p = 0; p < 7; p++) all += sum[p];
+	fprintf(stderr, "[stamps] %s: %.0f shader cycles per wave at %.2f GHz:", name, all / nslots, sum[7] / nslots / 1000.0 * 0.1);
+	for (int p = 0; p < 7; p++) if (phase[p]) fprintf(stderr, "  %s %.0f", phase[p], sum[p] / nslots);
 	fprintf(stderr, "\n");
 }
 
@@ -928,13 +912,25 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 	uint64_t *d_st = nullptr;
 	const size_t slots1 = (size_t)n * wps * 2, slots3 = (size_t)n * NT * 2;
 	if (stamps_on) {
-		if (hipMalloc(&d_st, std::max(std::max(slots1, slots3), (size_t)n * 4) * 64) != hipSuccess) return hipErrorOutOfMemory;
-		(void)hipMemset(d_st, 0, std::max(std::max(slots1, slots3), (size_t)n * 4) * 64);
+		if (hipMalloc(&d_st, std::max(std::max(slots1, slots3), (size_t)n * MQ * MW) * 64) != hipSuccess) return hipErrorOutOfMemory;
+		(void)hipMemset(d_st, 0, std::max(std::max(slots1, slots3), (size_t)n * MQ * MW) * 64);
+	}
+	if (stamps_on) {
+		int b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (pipe_analyse_kernel<false, false>), PW, 0);
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (pipe_masks_kernel<false, false>), 64 * MW, 0);
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, pipe_resolve_kernel<false>, K2T, K2_LDS);
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, pipe_pack_kernel<false>, PW, 0);
+		fprintf(stderr, "[occupancy API] workgroups per CU: analyse %d (x2 waves)  masks %d (x%d waves)  resolve %d  pack %d (x2 waves)\n", b1, b2, MW, b3, b4);
 	}
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	const bool timing = tune && tune->times_us;
 	if (timing) for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return hipErrorUnknown;
 	if (timing) (void)hipEventRecord(ev[0], s);
+	{
+		hipError_t e0 = hipMemsetAsync(pa.dcount, 0, (size_t)n * sizeof(uint32_t), s);
+		if (e0 != hipSuccess) return e0;
+	}
 	if (stamps_on) {
 		if (sg) hipLaunchKernelGGL((pipe_analyse_kernel<true, true>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, d_st);
 		else hipLaunchKernelGGL((pipe_analyse_kernel<false, true>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, d_st);
@@ -947,8 +943,26 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 	if (e != hipSuccess) return e;
 	if (timing) (void)hipEventRecord(ev[1], s);
 	if (seg) {
-		if (sg) hipLaunchKernelGGL(pipe_masks_kernel<true>, dim3(n * MQ), dim3(64 * MW), 0, s, pa);
-		else hipLaunchKernelGGL(pipe_masks_kernel<false>, dim3(n * MQ), dim3(64 * MW), 0, s, pa);
+		if (stamps_on) {
+			(void)hipMemsetAsync(d_st, 0, (size_t)n * MQ * MW * 64, s);
+			hipLaunchKernelGGL((pipe_masks_kernel<false, true>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, d_st);
+			(void)hipStreamSynchronize(s);
+			static const char *const ph[8] = {"tables", "sync", "list+first fetch", "entries", nullptr, nullptr, nullptr, nullptr};
+			report_stamps("K1b masks", d_st, (size_t)n * MQ * MW, ph);
+			{
+				std::vector<uint64_t> h((size_t)n * MQ * MW * 8);
+				(void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+				uint64_t t0 = ~0ull, t1 = 0;
+				for (size_t i = 0; i < h.size() / 8; i++) { t0 = std::min(t0, h[i * 8 + 5]); t1 = std::max(t1, h[i * 8 + 6]); }
+				std::vector<double> st_(h.size() / 8), en_(h.size() / 8);
+				for (size_t i = 0; i < st_.size(); i++) { st_[i] = (h[i * 8 + 5] - t0) * 0.01; en_[i] = (h[i * 8 + 6] - t0) * 0.01; }
+				std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end());
+				const size_t m = st_.size();
+				fprintf(stderr, "[timeline] K1b: wave starts (us) p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f | ends p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f\n",
+				        st_[0], st_[m / 4], st_[m / 2], st_[3 * m / 4], st_[m - 1], en_[0], en_[m / 4], en_[m / 2], en_[3 * m / 4], en_[m - 1]);
+			}
+		} else if (sg) hipLaunchKernelGGL((pipe_masks_kernel<true, false>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, (uint64_t *)nullptr);
+		else hipLaunchKernelGGL((pipe_masks_kernel<false, false>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, (uint64_t *)nullptr);
 		e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
@@ -975,7 +989,7 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 		(void)hipMemsetAsync(d_st, 0, slots3 * 64, s);
 		hipLaunchKernelGGL(pipe_pack_kernel<true>, dim3(n * NT), dim3(PW), 0, s, pa, d_st);
 		(void)hipStreamSynchronize(s);
-		static const char *const ph3[8] = {"loads+tables", "sync", "perm+sizes", "sync", "scan+offsets", "emit", "sync+pairs+sync", "flush"};
+		static const char *const ph3[8] = {"loads+tables", "sync", "perm+sizes", "sync", "scan+offsets", "emit", "sync+pairs+sync+flush", nullptr};
 		report_stamps("K3 pack", d_st, slots3, ph3);
 		(void)hipFree(d_st);
 	} else hipLaunchKernelGGL(pipe_pack_kernel<false>, dim3(n * NT), dim3(PW), 0, s, pa, (uint64_t *)nullptr);

@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- CompaCT encode+decode throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|4|5]
     (N > 1: launched by the driver as python -m torch.distributed.run ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one batch: 256 device-resident synthetic 12-bit 512x512
-CT slices (BASELINE config 2) are encoded to byte-exact .cct files (HIP transform+pack kernel,
-device DEFLATE bit-identical to zlib level 9, one packed D2H into a page-locked archive) and those files are
-decoded back to rasters in HBM (archive H2D, device INFLATE, HIP token/scatter kernel).  Three distinct batches rotate so the working set
-(3 x 134 MB) exceeds the 256 MiB Infinity Cache.  Slices shard across GPUs with no data-path
-collective (weak scaling: 256 slices per GPU per step); the only exchange is the all-gather of
-the per-slice compressed sizes over RCCL.
+Workloads (BASELINE.json `configs`):
+  --config 2 (default, the headline)  256 device-resident synthetic 12-bit 512x512 CT slices per GPU and step: encoded to
+             byte-exact .cct files (transform+pack kernels, device DEFLATE bit-identical to zlib level 9, one packed D2H
+             into a page-locked archive) and decoded back to rasters in HBM (archive H2D, device INFLATE, token/scatter
+             kernel).  Three distinct batches rotate so the working set (3 x 134 MB) exceeds the 256 MiB Infinity Cache.
+  --config 4  the same pipeline on 512 slices of 1024x1024 per step (1.07 GB of pixels: HBM for certain).
+  --config 5  decode only: the archives of config 2 are encoded once outside the timed region; a step decodes one.
+Slices shard across GPUs with no data-path collective (weak scaling: the same number of slices per GPU per step); the
+only exchange is the all-gather of the per-slice compressed sizes over RCCL.
 
 One JSON line on stdout (rank 0): metric/value as the driver contract says, plus
-  roofline      dominant transform+pack kernel: algorithmic HBM-read bytes (2 B/pixel)
-                / mean kernel time from HIP events on the launch stream, against 8 TB/s;
-  cpu_baseline  the CPU oracle (C port of the reference algorithm, 1 core) on a bounded sample;
-  stages        per-stage throughput so the DEFLATE-bound end-to-end number and the HBM-bound
-                kernel number are both visible.
+  roofline      the transform+pack stage (the four kernels of encode_pipe.hip; decode-only: INFLATE + decode kernel):
+                algorithmic HBM bytes per launch / mean stage time from HIP events recorded on the library's own stream
+                around every launch of the timed region, against 8 TB/s; `traffic` from profiles/ only while the kernel
+                source still has the hash the counters were collected with;
+  rooflines     the same arithmetic for the other device stages (DEFLATE, INFLATE, decode kernel);
+  cpu_baseline  the CPU oracle (C port of the reference algorithm): one core, and all host cores through a process
+                pool (the reference's own fan-out, scripts/evaluate.py:107), CPU model and core count stated;
+  stages        per-stage times, single-slice latency through codec.core (BASELINE configs[0] shape of call).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -34,58 +40,141 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W = H = 512
 BS = 16
-SLICES_PER_GPU = 256
 N_ROT = 3
 HBM_PEAK_GBS = 8000.0
+PIPE_SRC = os.path.join(PKG, "csrc", "encode_pipe.hip")
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_encode.json")
+WORKLOADS = {2: (512, 256), 4: (1024, 512), 5: (512, 256)}  # config -> (edge, slices per GPU and step)
 
 
-def make_batches(rank, n_slices):
-    """Batch 0 = ct_phantom(seed) for n_slices distinct seeds (rank-disjoint); batches 1, 2 are its
-    left-right / up-down mirrors: distinct bytes in HBM, same statistics, cheap to build."""
-    from concurrent.futures import ProcessPoolExecutor
-    from cct_hip.synth import ct_phantom
-    seeds = [rank * n_slices + i for i in range(n_slices)]
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+def _usable_cpus():
+    """CPUs this process may really use: affinity mask, capped by a cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _phantom_job(args):
+    from cct_hip.synth import ct_phantom
+    return ct_phantom(*args)
+
+
+def make_batches(rank, n_slices, edge=512):
+    """Batch 0 = ct_phantom(seed) for distinct seeds (rank-disjoint; 1024x1024: 32 distinct phantoms, tiled, which keeps
+    the generation time of 512 slices bounded); batches 1, 2 are its left-right / up-down mirrors: distinct bytes in
+    HBM, same statistics.  Uses a process pool: call it BEFORE anything initialises the GPU (fork)."""
+    from concurrent.futures import ProcessPoolExecutor
+    distinct = n_slices if edge <= 512 else min(n_slices, 32)
+    seeds = [(rank * n_slices + i, edge) for i in range(distinct)]
+    workers = max(1, min(16, _usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if workers > 1:
         with ProcessPoolExecutor(workers) as ex:
-            imgs = list(ex.map(ct_phantom, seeds, chunksize=8))
-    except Exception:  # noqa: BLE001 - restricted environments: fall back to in-process generation
-        imgs = [ct_phantom(s) for s in seeds]
-    b0 = np.stack(imgs)
+            imgs = list(ex.map(_phantom_job, seeds, chunksize=4))
+    else:
+        imgs = [_phantom_job(s) for s in seeds]
+    b0 = np.stack([imgs[i % distinct] for i in range(n_slices)])
     return [b0, np.ascontiguousarray(b0[:, :, ::-1]), np.ascontiguousarray(b0[:, ::-1, :])][:N_ROT]
 
 
-def cpu_baseline(batch, budget_s=20.0):
-    """Oracle (C restatement of the reference path, 1 thread) on a bounded sample of the workload."""
+def _oracle_job(img):
     from oracle import oracle
     t0 = time.perf_counter()
-    n = 0
+    f = oracle.encode(img)
+    t1 = time.perf_counter()
+    oracle.decode(f)
+    return t1 - t0, time.perf_counter() - t1
+
+
+def cpu_baseline(batch, budget_s=10.0):
+    """The CPU restatement (oracle/compact_oracle.c) on a bounded sample of the workload: one core, then every usable
+    core through a process pool as scripts/evaluate.py:107 fans slices out.  Call before the GPU is initialised."""
+    from concurrent.futures import ProcessPoolExecutor
+    px = batch.shape[1] * batch.shape[2]
+    t0 = time.perf_counter()
+    n1, te, td = 0, 0.0, 0.0
     for img in batch:
-        f = oracle.encode(img)
-        oracle.decode(f)
-        n += 1
+        e, d = _oracle_job(img)
+        te += e; td += d; n1 += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": round(n * W * H / dt / 1e6, 3), "unit": "MPixels/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} slices of batch 0, encode+decode each, oracle/compact_oracle.c single thread"}
+    dt1 = time.perf_counter() - t0
+    cores = _usable_cpus()
+    n_all = min(len(batch), max(cores, int(n1 * cores * 0.8)))
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(cores) as ex:
+        list(ex.map(_oracle_job, batch[:n_all], chunksize=max(1, n_all // (cores * 4))))
+    dt_all = time.perf_counter() - t0
+    return {"value": round(n1 * px / dt1 / 1e6, 3), "unit": "MPixels/s", "cores": 1, "kind": "port",
+            "sample": f"first {n1} slices of batch 0, encode+decode each, oracle/compact_oracle.c single thread",
+            "encode_MPix_s": round(n1 * px / te / 1e6, 3), "decode_MPix_s": round(n1 * px / td / 1e6, 3),
+            "all_cores": {"value": round(n_all * px / dt_all / 1e6, 3), "unit": "MPixels/s", "cores": cores,
+                          "sample": f"first {n_all} slices of batch 0 over a pool of {cores} processes (incl. pool start)"},
+            "host_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
+            "reference_python_survey_container": {"encode_MPix_s": 0.105, "decode_MPix_s": 0.157,
+                                                  "note": "reference src/codec timed in the survey container (SURVEY 6), 1 core"}}
+
+
+def pmc_traffic():
+    """HBM traffic of the transform+pack stage from the committed --pmc run, only while the kernel source is unchanged."""
+    try:
+        with open(PMC_JSON) as f:
+            pmc = json.load(f)
+        with open(PIPE_SRC, "rb") as f:
+            sha = hashlib.sha1(f.read()).hexdigest()
+        if pmc.get("source_sha1") == sha:
+            return pmc["traffic_bytes_per_launch"], os.path.relpath(PMC_JSON, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, same launch shape)"
+        return None, "stale: " + os.path.relpath(PMC_JSON, ROOT) + " was collected with another encode_pipe.hip"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slices", type=int, default=SLICES_PER_GPU, help="slices per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
+    ap.add_argument("--slices", type=int, default=None, help="slices per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
     args = ap.parse_args()
+    edge, n = WORKLOADS[args.config]
+    if args.slices:
+        n = args.slices
+    if args.steps is None:
+        args.steps = 50 if edge == 512 else 8
+    W = H = edge
+    npx = n * W * H
+    decode_only = args.config == 5
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- host-side work that forks: before any GPU / RCCL initialisation
+    batches = make_batches(rank, n, edge)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batches[0])
+
     dist = None
     if args.gpus > 1 or world > 1:
         import torch
@@ -100,34 +189,24 @@ def main():
     L = _ffi.lib()
     _ffi.check(L.cct_init(local_rank))
     info = cct_hip.device_info()
-    ncpu = os.cpu_count() or 1
-    # host team: the library sizes it from the CPUs this process may use (cgroup quota aware); ranks of one node
-    # share them
+    # host team: the library sizes it from the CPUs this process may use (cgroup quota aware); ranks of one node share them
     zt = C.c_int(0)
     _ffi.check(L.cct_get_option(b"zlib_threads", C.byref(zt)))
     zthreads = max(1, zt.value // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     if os.environ.get("CCT_HOST_THREADS"):
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
-
-    if os.environ.get("CCT_DEFLATE_WAYS"):
-        _ffi.check(L.cct_set_option(b"deflate_ways", int(os.environ["CCT_DEFLATE_WAYS"])))
-    if os.environ.get("CCT_WG_THREADS"):
-        _ffi.check(L.cct_set_option(b"wg_threads", int(os.environ["CCT_WG_THREADS"])))
-    if os.environ.get("CCT_DEFLATE_GRAPH"):
-        _ffi.check(L.cct_set_option(b"deflate_graph", int(os.environ["CCT_DEFLATE_GRAPH"])))
-    if os.environ.get("CCT_DEVICE_INFLATE"):
-        _ffi.check(L.cct_set_option(b"device_inflate", int(os.environ["CCT_DEVICE_INFLATE"])))
+    for env, key in (("CCT_DEFLATE_WAYS", b"deflate_ways"), ("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
+                     ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path")):
+        if os.environ.get(env):
+            _ffi.check(L.cct_set_option(key, int(os.environ[env])))
     dev_deflate, dev_inflate = C.c_int(0), C.c_int(0)
     _ffi.check(L.cct_get_option(b"device_deflate", C.byref(dev_deflate)))
     _ffi.check(L.cct_get_option(b"device_inflate", C.byref(dev_inflate)))
     cfg = cct_hip.default_config()
     cfg["verbose"] = False
     flags, bs, eof, magic, ch, bpc = cct_hip.codec_params(cfg, np.uint16)
-    n = args.slices
-    npx = n * W * H
 
-    batches = make_batches(rank, n)
     d_imgs = [cct_hip.DeviceBuffer.from_numpy(b) for b in batches]
     # Three buffer sets: while step k is decoded (device INFLATE + decode kernel on the decode stream) step k+1 is
     # already being encoded (transform+pack + device DEFLATE).  Host threads drive the C ABI; ctypes drops the GIL.
@@ -142,7 +221,7 @@ def main():
     h_psizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
     h_status = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
     acc = {"enc_kernel": 0.0, "d2h": 0.0, "deflate": 0.0, "inflate": 0.0, "dec_kernel": 0.0, "enc": 0.0, "dec": 0.0,
-           "gather": 0.0, "payload_bytes": 0, "file_bytes": 0}
+           "gather": 0.0, "payload_bytes": 0, "file_bytes": 0, "n_enc": 0, "n_dec": 0}
     from concurrent.futures import ThreadPoolExecutor
     # two encode threads: the library gives the device lock back while a batch's files are still on the wire, so
     # the next batch's kernels start during that copy
@@ -160,9 +239,11 @@ def main():
             acc["enc_kernel"] += tm[0]; acc["d2h"] += tm[1]; acc["deflate"] += tm[2]
             acc["enc"] += (time.perf_counter() - t0) * 1e3
             acc["payload_bytes"] += int(h_psizes[k].sum()); acc["file_bytes"] += int(h_sizes[k].sum())
+            acc["n_enc"] += 1
 
     def dec_step(k, enc_future, record):
-        enc_future.result()
+        if enc_future is not None:
+            enc_future.result()
         t0 = time.perf_counter()
         tm = (C.c_float * 6)()
         st = np.zeros(n, dtype=np.uint32)
@@ -172,6 +253,7 @@ def main():
         if record:
             acc["inflate"] += tm[3]; acc["dec_kernel"] += tm[4]
             acc["dec"] += (time.perf_counter() - t0) * 1e3
+            acc["n_dec"] += 1
 
     in_flight = []
     state = {"sizes": None}
@@ -182,6 +264,9 @@ def main():
             k = i % NSET
             while len(in_flight) >= (NSET if overlap else 1):
                 in_flight.pop(0).result()       # buffer set k is free again
+            if decode_only:
+                in_flight.append(pool_dec.submit(dec_step, k, None, record))
+                continue
             e = pool_enc.submit(enc_step, i, k, record)
             in_flight.append(pool_dec.submit(dec_step, k, e, record))
             if not overlap:
@@ -206,6 +291,11 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    if decode_only:  # the archives are produced once, outside the timed region
+        for k in range(NSET):
+            enc_step(k, k, True)
+        state["sizes"] = gather_sizes(h_sizes[0], dist, local_rank)
+        acc["n_enc"] = max(1, acc["n_enc"])
     run_steps(0, args.warmup, False)
     barrier()
     t_start = time.perf_counter()
@@ -220,7 +310,8 @@ def main():
 
     # ---- verification outside the timed region: exact round trip + oracle bytes on a sample
     last_i = args.warmup + args.steps - 1
-    last, kset = last_i % len(batches), last_i % NSET
+    kset = last_i % NSET
+    last = kset % len(batches) if decode_only else last_i % len(batches)
     back = d_back[kset].download(np.uint16, npx).reshape(n, W, H)
     verified = bool(np.array_equal(back, batches[last]))
     from oracle import oracle
@@ -228,55 +319,88 @@ def main():
         verified &= oracle.encode(batches[last][j]) == h_arch[kset][int(h_offs[kset][j]):int(h_offs[kset][j + 1])].tobytes()
     all_sizes = state["sizes"]
 
+    # ---- single-slice latency through the reference's class surface (BASELINE configs[0] shape of call)
+    single = None
+    if rank == 0:
+        from codec.core import Decoder, Encoder
+        img = batches[0][0]
+        te, td = [], []
+        for _ in range(7):
+            t0 = time.perf_counter(); f = Encoder(cfg, img).encode(); t1 = time.perf_counter()
+            Decoder(cfg, f).decode(); t2 = time.perf_counter()
+            te.append((t1 - t0) * 1e3); td.append((t2 - t1) * 1e3)
+        single = {"encode_ms": round(sorted(te)[3], 3), "decode_ms": round(sorted(td)[3], 3),
+                  "note": f"codec.core.Encoder.encode() / Decoder.decode() of one {W}x{H} slice, host arrays in and out, median of 7"}
+
     if rank == 0:
         K = max(1, args.steps)
+        ne, nd = max(1, acc["n_enc"]), max(1, acc["n_dec"])
         ms_step = elapsed * 1e3 / K
         value = world * npx * K / elapsed / 1e6
-        enc_kernel_ms = acc["enc_kernel"] / K
-        alg_bytes = 2.0 * npx  # HBM-read definition, 2 B per pixel per launch
-        achieved = alg_bytes / (enc_kernel_ms * 1e-3) / 1e9
-        payload_per_launch = acc["payload_bytes"] / K
-        traffic, traffic_src = None, None
-        try:  # PMC traffic is collected by separate rocprofv3 --pmc runs (it cannot be read from inside this process)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_encode.json")) as f:
-                pmc = json.load(f)
-            traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_encode.json (FETCH_SIZE x2 + WRITE_SIZE, same 256-slice launch)"
-        except (OSError, KeyError, ValueError):
-            pass
+        enc_kernel_ms = acc["enc_kernel"] / ne
+        payload_per_launch = acc["payload_bytes"] / ne
+        file_per_launch = acc["file_bytes"] / ne
+        traffic, traffic_src = pmc_traffic() if (edge == 512 and n == 256) else (None, None)
+
+        def roof(kernel, alg_bytes, ms, extra=None):
+            gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            r = {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "avg_ms": round(ms, 4)}
+            if extra:
+                r.update(extra)
+            return r
+
+        pack = roof("transform+pack stage: pipe_analyse_kernel + pipe_masks_kernel + pipe_resolve_kernel + pipe_pack_kernel "
+                    "(image -> token payload), events around the four launches", 2.0 * npx, enc_kernel_ms,
+                    {"traffic": traffic, "traffic_source": traffic_src,
+                     "read_plus_write_GBs": round((2.0 * npx + payload_per_launch) / (enc_kernel_ms * 1e-3) / 1e9, 1),
+                     "avg_kernel_ms": round(enc_kernel_ms, 4)})
+        deflate_ms, inflate_ms, dec_ms = acc["deflate"] / ne, acc["inflate"] / nd, acc["dec_kernel"] / nd
+        others = {
+            "deflate": roof("device DEFLATE pass (sort, match, lazy parse, trees, emit: ~25 kernels as one graph)",
+                            payload_per_launch + file_per_launch, deflate_ms),
+            "inflate": roof("inflate_kernel (device INFLATE)", file_per_launch + payload_per_launch, inflate_ms),
+            "decode": roof("decode_kernel (tokens -> raster)", payload_per_launch + 2.0 * npx, dec_ms),
+        }
+        if decode_only:
+            main_roof = roof("decode stages: inflate_kernel + decode_kernel (archive -> rasters)", file_per_launch + 2.0 * npx,
+                             inflate_ms + dec_ms, {"traffic": None, "traffic_source": None})
+        else:
+            main_roof = pack
+        what = "decode only" if decode_only else "encode to .cct + decode back"
         out = {
-            "metric": "MPixels/s encode+decode, 12-bit 512x512 CT batch, bytes-exact",
+            "metric": "MPixels/s encode+decode, 12-bit 512x512 CT batch, bytes-exact" if not decode_only
+            else "MPixels/s decode, 12-bit 512x512 CT batch, bytes-exact",
             "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batch of {n} synthetic 512x512 uint16 CT slices per GPU, "
-                                   f"encode to .cct + decode back, {N_ROT} rotating device-resident batches",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of {n} synthetic {W}x{H} uint16 CT slices per GPU, "
+                                   f"{what}, {N_ROT} rotating device-resident batches",
                        "slices_per_gpu": n, "width": W, "height": H, "block_size": bs,
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)"},
-            "roofline": {"kernel": "encode_tiles_kernel (transform+pack, image -> token payload)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "read_plus_write_GBs": round((alg_bytes + payload_per_launch) / (enc_kernel_ms * 1e-3) / 1e9, 1),
-                         "avg_kernel_ms": round(enc_kernel_ms, 4)},
+            "roofline": main_roof,
+            "rooflines": others if decode_only else dict(others, transform_pack=pack),
             "stages": {
                 "encode_transform_pack_MPix_s": round(npx / (enc_kernel_ms * 1e-3) / 1e6, 1),
-                "decode_tokens_scatter_MPix_s": round(npx / (acc["dec_kernel"] / K * 1e-3) / 1e6, 1),
-                "encode_end_to_end_MPix_s": round(npx / (acc["enc"] / K * 1e-3) / 1e6, 2),
-                "decode_end_to_end_MPix_s": round(npx / (acc["dec"] / K * 1e-3) / 1e6, 2),
-                "ms": {k: round(acc[k] / K, 3) for k in ("enc_kernel", "d2h", "deflate", "inflate", "dec_kernel", "enc",
-                                                         "dec", "gather")},
+                "decode_tokens_scatter_MPix_s": round(npx / (dec_ms * 1e-3) / 1e6, 1),
+                "encode_end_to_end_MPix_s": round(npx / (acc["enc"] / ne * 1e-3) / 1e6, 2),
+                "decode_end_to_end_MPix_s": round(npx / (acc["dec"] / nd * 1e-3) / 1e6, 2),
+                "ms": {"enc_kernel": round(enc_kernel_ms, 3), "d2h": round(acc["d2h"] / ne, 3), "deflate": round(deflate_ms, 3),
+                       "inflate": round(inflate_ms, 3), "dec_kernel": round(dec_ms, 3), "enc": round(acc["enc"] / ne, 3),
+                       "dec": round(acc["dec"] / nd, 3), "gather": round(acc["gather"] / K, 3)},
                 "deflate": "device (deflate_kernels.hip, byte-identical to zlib 1.2.11 level 9)" if dev_deflate.value
                 else "host libz thread team", "inflate": "device (inflate_kernels.hip, speculative lane-parallel decode)" if dev_inflate.value
                 else "host libz thread team",
                 "note": "enc/dec = wall time of the C calls; with overlap two encode calls are in flight, so enc includes "
                         "the wait for the device lock",
-                "host_threads": zthreads, "host_cpus": ncpu,
-                "compression_ratio": round(2.0 * npx * K / max(1, acc["file_bytes"]), 4)},
+                "host_threads": zthreads, "host_cpus": os.cpu_count() or 1,
+                "compression_ratio": round(2.0 * npx / max(1.0, file_per_launch), 4),
+                "single_slice_latency": single},
             "device": info["name"], "verified": verified,
-            "sizes_gathered": int(np.asarray(all_sizes).size),
+            "sizes_gathered": int(np.asarray(all_sizes).size) if all_sizes is not None else 0,
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batches[0])
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

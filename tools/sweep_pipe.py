@@ -31,6 +31,7 @@ def main():
     stride = payload_stride(w, w, 16)
     d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
     params = codec_params(cct_hip.default_config(), np.uint16)
+    print("device:", cct_hip.device_info(), flush=True)
     L.cct_set_option(b"pipe_timing", 1)
     reps = 2 if os.environ.get("CCT_PIPE_STAMPS") else 12
     for tpw in tpws:
