@@ -76,10 +76,11 @@ struct ShapeTables {  // everything that depends on (width, height) only; lives 
 	// staged pipeline (encode_pipe.hip): every tile is a 16x16 grid of 4x4-pixel traversal blocks
 	bool pipe = false;
 	uint32_t *d_ptab = nullptr;       // n_orient * 128 * 4
+	uint32_t *d_ptab2 = nullptr;      // n_orient * 2 * 64 * 4
 	uint32_t *d_btab = nullptr;       // n_orient * 256
 	uint32_t *d_otab = nullptr;       // 4 * 16
 	uint32_t *d_ttab = nullptr;       // 16 * 4
-	uint32_t *d_tile_last = nullptr;  // n_orient
+	PipeTiles tiles;                  // host copy: travels in the kernel arguments
 };
 
 struct Context {
@@ -112,7 +113,7 @@ struct Context {
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
-	DevBuf e_toff, e_pairrec, e_spill, e_dlist, e_dcount;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
+	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	// decode workspaces
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	DevBuf h_stage;  // pinned host staging (payloads)
@@ -220,7 +221,7 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 	const int nt = (int)org.size();
 	const int no = t.n_orient;
 	std::vector<uint16_t> rtab((size_t)no * 256, 0xFFFF);
-	std::vector<uint32_t> tile_last(no, 0);
+	std::vector<uint32_t> tile_last(no, 0), tile_mid(no, 0);
 	std::vector<std::vector<int>> bpat;  // block orientations: raster index (row*4+col) of the 16 positions
 	for (int ti = 0; ti < nt; ti++) {
 		const int32_t *k = O.data() + (size_t)ti * 4096;
@@ -246,6 +247,7 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 			slot = ent;
 		}
 		tile_last[to] = (uint32_t)(k[4095] - (int)org[ti]);
+		tile_mid[to] = (uint32_t)(k[2047] - (int)org[ti]);
 	}
 	for (uint16_t e : rtab) if (e == 0xFFFF) return;
 	// per-lane entries of a tile workgroup and the block table of the mask kernel
@@ -275,6 +277,42 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 			}
 		}
 	}
+	// half-tile waves: the 64 block pairs whose blocks lie in the first / second 128 traversal blocks, raster order
+	std::vector<uint32_t> ptab2((size_t)no * 2 * 64 * 4, 0);
+	for (int to = 0; to < no; to++)
+		for (int half = 0; half < 2; half++) {
+			int cnt = 0;
+			for (int lane = 0; lane < 128; lane++) {
+				const uint32_t *e = ptab.data() + ((size_t)to * 128 + lane) * 4;
+				const int ka = (int)(e[0] & 0xFF), kb = (int)((e[0] >> 16) & 0xFF);
+				if ((ka >> 7) != (kb >> 7)) return;  // a pair of blocks straddles the halves: not the structure assumed
+				if ((ka >> 7) != half) continue;
+				if (cnt == 64) return;
+				uint32_t *d = ptab2.data() + (((size_t)to * 2 + half) * 64 + cnt) * 4;
+				d[0] = e[0]; d[1] = e[1]; d[2] = e[2];
+				d[3] = (uint32_t)((lane >> 3) * 4 * width + (lane & 7) * 8);
+				cnt++;
+			}
+			if (cnt != 64) return;
+			// the half must be a 64x32 (block rows r0..r0+7) or a 32x64 (block-pair columns c0..c0+3) rectangle
+			const uint32_t *d0 = ptab2.data() + ((size_t)to * 2 + half) * 64 * 4;
+			uint32_t geom = 0xFFFFFFFFu;
+			for (int vertical = 0; vertical < 2 && geom == 0xFFFFFFFFu; vertical++)
+				for (int first = 0; first < 16 && geom == 0xFFFFFFFFu; first += vertical ? 4 : 8) {
+					bool ok = true;
+					for (int l = 0; l < 64 && ok; l++) {
+						const uint32_t want = vertical ? (uint32_t)((l >> 2) * 4 * width + (first + (l & 3)) * 8)
+						                               : (uint32_t)((first + (l >> 3)) * 4 * width + (l & 7) * 8);
+						ok = d0[l * 4 + 3] == want;
+					}
+					if (ok) geom = (uint32_t)vertical | (uint32_t)first << 8;
+				}
+			if (geom == 0xFFFFFFFFu) return;
+			t.tiles.geom[to * 2 + half] = geom;
+		}
+	if (nt > 256) return;
+	for (int ti = 0; ti < nt; ti++) { t.tiles.org[ti] = org[ti]; t.tiles.orient[ti] = orient[ti]; }
+	for (int to = 0; to < no; to++) { t.tiles.last[to] = tile_last[to]; t.tiles.mid[to] = tile_mid[to]; }
 	std::vector<uint32_t> otab(64, 0);
 	for (size_t bo = 0; bo < bpat.size(); bo++) {
 		const std::vector<int> &pat = bpat[bo];
@@ -312,14 +350,14 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 	}
 	if (hipMalloc(&t.d_ptab, ptab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_btab, btab.size() * 4) != hipSuccess) return;
+	if (hipMalloc(&t.d_ptab2, ptab2.size() * 4) != hipSuccess) return;
+	if (hipMemcpy(t.d_ptab2, ptab2.data(), ptab2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMalloc(&t.d_otab, otab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_ttab, ttab.size() * 4) != hipSuccess) return;
-	if (hipMalloc(&t.d_tile_last, tile_last.size() * 4) != hipSuccess) return;
 	if (hipMemcpy(t.d_ptab, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_btab, btab.data(), btab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_otab, otab.data(), otab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMemcpy(t.d_ttab, ttab.data(), ttab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
-	if (hipMemcpy(t.d_tile_last, tile_last.data(), tile_last.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	t.pipe = true;
 }
 
@@ -501,23 +539,22 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	a.ws_lidx = (uint32_t *)g_ctx.e_lidx.p; a.ws_lmask = (uint64_t *)g_ctx.e_lmask.p; a.ws_lcur = (uint8_t *)g_ctx.e_lcur.p;
 	const ShapeTables *tb = nullptr;
 	if ((flags & CCT_FLAG_FRACTAL) && bs == 16 && g_ctx.use_tiles) { if ((rc = get_tables(width, height, &tb))) return rc; }
-	if (tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && g_ctx.use_tiles == 1 && !g_ctx.dbg_skip) {
+	if (tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && g_ctx.use_tiles == 1) {
 		const int NT = tb->n_tiles;
 		if ((rc = g_ctx.e_role.ensure(per))) return rc;
-		if ((rc = g_ctx.e_toff.ensure((size_t)n * (NT + 1) * 4))) return rc;
+		if ((rc = g_ctx.e_toff.ensure((size_t)n * (2 * NT + 1) * 4))) return rc;
 		if ((rc = g_ctx.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
 		if ((rc = g_ctx.e_spill.ensure(per * 4))) return rc;
-		if ((rc = g_ctx.e_dlist.ensure(per * 4))) return rc;
-		if ((rc = g_ctx.e_dcount.ensure((size_t)n * 4))) return rc;
+		if ((rc = g_ctx.e_tflag.ensure((size_t)n * (NT + 1) * 4 + (size_t)n * NT * 4))) return rc;
 		PipeArgs pa{};
 		pa.e = a;
-		pa.tile_org = tb->d_org; pa.tile_orient = tb->d_orient; pa.ptab = tb->d_ptab; pa.btab = tb->d_btab; pa.otab = tb->d_otab;
-		pa.ttab = tb->d_ttab; pa.tile_last = tb->d_tile_last;
+		pa.tiles = tb->tiles; pa.ptab = tb->d_ptab; pa.ptab2 = tb->d_ptab2; pa.btab = tb->d_btab; pa.otab = tb->d_otab;
+		pa.ttab = tb->d_ttab;
 		pa.n_orient = tb->n_orient; pa.n_tiles = NT; pa.row_pitch = width;
 		pa.ssz = (uint8_t *)g_ctx.e_lcur.p; pa.mask = (uint64_t *)g_ctx.e_lmask.p; pa.roles = (uint8_t *)g_ctx.e_role.p;
 		pa.spec = (uint32_t *)g_ctx.e_lidx.p; pa.toff = (uint32_t *)g_ctx.e_toff.p; pa.pairrec = (uint8_t *)g_ctx.e_pairrec.p;
 		pa.spill_idx = (uint32_t *)g_ctx.e_spill.p;
-		pa.dlist = (uint32_t *)g_ctx.e_dlist.p; pa.dcount = (uint32_t *)g_ctx.e_dcount.p;
+		pa.tflag = (uint32_t *)g_ctx.e_tflag.p; pa.tcount = pa.tflag + (size_t)n * NT; pa.tlist = pa.tcount + n;
 		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
 		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream, &tune));
 		g_ctx.last_path = 1;

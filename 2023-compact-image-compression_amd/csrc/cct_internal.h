@@ -52,26 +52,35 @@ hipError_t launch_encode_tiles(const TileEncArgs &ta, int n, hipStream_t s);
 constexpr int PIPE_MAX_NB = 65536;          // blocks per slice (the resolve kernel keeps role[] in LDS)
 constexpr int PIPE_PAIR_REC = 80;           // bytes per meshed-pair record: jump byte + up to 64 token bytes, padded to 16
 constexpr uint32_t CCT_ST_INTERNAL = 0x80000000u;  // the kernels disagree about a size: a bug, never a data property
+struct PipeTiles {             // small per-shape tables carried IN the kernel arguments: one scalar load, no pointer to chase
+	uint32_t org[256];           // raster index of each tile's top-left pixel
+	uint8_t orient[256];         // tile orientation
+	uint32_t last[TILE_MAX_ORIENT];  // raster offset inside the tile of the tile's last traversal position
+	uint32_t mid[TILE_MAX_ORIENT];   // the same for position 2047 (the last pixel of the first half tile)
+	uint32_t geom[TILE_MAX_ORIENT * 2];  // region of half h of orientation o: bit 0 = vertical split (32x64 pixels), bits 8.. = first
+	                                     // block row (horizontal split) or first block-pair column (vertical split)
+};
 struct PipeArgs {
 	EncArgs e;                   // e.lut must be the traversal table
-	const uint32_t *tile_org;    // n_tiles: raster index of each tile's top-left pixel
-	const uint8_t *tile_orient;  // n_tiles: tile orientation (index into rtab / tile_last)
+	PipeTiles tiles;
 	const uint32_t *ptab;        // n_orient * 128 entries of 4 dwords, one per lane of a tile workgroup (lane = block row * 8 + block pair):
 	                             //   [0] traversal block index | orientation << 8 of the left block, the same << 16 for the right block
 	                             //   [1], [2] raster offset inside the tile of the pixel that precedes the left / right block in
 	                             //   traversal order (0xFFFFFFFF: the block opens the tile)
+	const uint32_t *ptab2;       // n_orient * 2 * 64 entries of 4 dwords, one per lane of a half-tile wave (half = 128 traversal blocks):
+	                             //   [0..2] as ptab, [3] raster offset inside the tile of the lane's 8x4-pixel region
 	const uint32_t *btab;        // n_orient * 256: traversal block of a tile -> raster offset of its top-left pixel | orientation << 24
 	const uint32_t *otab;        // 4 * 16 dwords per block orientation: eight v_perm selectors, quadrant choice bits
 	const uint32_t *ttab;        // 16 * 4 dwords: token byte selectors and length for the 16 two-byte masks of a 4-pixel group
-	const uint32_t *tile_last;   // n_orient: raster offset inside the tile of the tile's last traversal position
 	int n_orient, n_tiles, row_pitch;
 	uint8_t *ssz;                // n * NB: token bytes of every block emitted alone after its traversal predecessor | 0x80 if difficult
 	uint64_t *mask;              // n * NB: candidate fit masks, valid for difficult blocks
-	uint32_t *dlist;             // n * NB: difficult blocks of a slice in any order: block | cur << 24 (work list of the mask kernel)
-	uint32_t *dcount;            // n: entries of dlist
+	uint32_t *tflag;             // n * n_tiles: tile has difficult blocks; then
+	uint32_t *tcount;            // n (contiguous with tflag, one memset): tiles listed per slice
+	uint32_t *tlist;             // n * n_tiles: the listed tiles of every slice (work of the mask kernel)
 	uint8_t *roles;              // n * NB: the block partition
 	uint32_t *spec;              // n * NB: leaders: pair record << 8 | group bytes; blocks after a meshed block: predecessor pixel
-	uint32_t *toff;              // n * (n_tiles + 1): payload offset of every tile's first token, then the token total
+	uint32_t *toff;              // n * (2 * n_tiles + 1): payload offset of every half tile's first token, then the token total
 	uint8_t *pairrec;            // n * (NB / 2) * PIPE_PAIR_REC
 	uint32_t *spill_idx;         // n * NB: ordered difficult-block list beyond the LDS capacity of the resolve kernel
 };

@@ -35,9 +35,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define LDS(T) __attribute__((address_space(3))) T
 
 constexpr int PW = 128;             // lanes per workgroup of K1 / K3: one 64x64 tile, a pair of blocks per lane
-constexpr int TILE_BYTES = 8192;
-constexpr int STG_BYTES = 10496;    // payload bytes of one tile: 15 (alignment) + 193 * 32.5 + 63 * 65 + EOF + pad
-constexpr int PAIR_CAP = 256;       // leaders per tile
 
 // ---- packed 16-bit arithmetic (two pixels per instruction) --------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -214,6 +211,7 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 	const bool seg = (a.e.flags & CCT_FLAG_SEGMENTATION) != 0;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	uint8_t *ssz = a.ssz + (size_t)sl * NB;
+	uint64_t *gmask = a.mask + (size_t)sl * NB;
 	const int pitch = a.row_pitch;
 	const u32x4 *ptab = reinterpret_cast<const u32x4 *>(a.ptab);
 
@@ -221,20 +219,20 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 	const int by = tid >> 3, bxp = tid & 7;
 	const size_t reg_off = (size_t)(by * 4) * pitch + bxp * 8;
 	auto load_rows = [&](int tile, u32x4 r[4]) {
-		const uint16_t *p = img + a.tile_org[tile] + reg_off;
+		const uint16_t *p = img + a.tiles.org[tile] + reg_off;
 #pragma unroll
 		for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
 	};
 	// pixels before the lane's two blocks (traversal order); a block that opens its tile follows the previous tile's last pixel
 	auto load_prev = [&](int tile, const u32x4 &ent, uint32_t &pa, uint32_t &pb) {
-		const uint32_t org = a.tile_org[tile];
-		const uint32_t porg = tile > 0 ? a.tile_org[tile - 1] + a.tile_last[a.tile_orient[tile - 1]] : 0u;
+		const uint32_t org = a.tiles.org[tile];
+		const uint32_t porg = tile > 0 ? a.tiles.org[tile - 1] + a.tiles.last[a.tiles.orient[tile - 1]] : 0u;
 		pa = img[ent.y != 0xFFFFFFFFu ? org + ent.y : porg];
 		pb = img[ent.z != 0xFFFFFFFFu ? org + ent.z : porg];
 	};
 	u32x4 r[4], ent;
 	load_rows(t0, r);
-	ent = ptab[(int)a.tile_orient[t0] * PW + tid];
+	ent = ptab[(int)a.tiles.orient[t0] * PW + tid];
 	if (tid < 64) otab[tid] = a.otab[tid];
 	uint32_t pvA, pvB;
 	load_prev(t0, ent, pvA, pvB);
@@ -251,13 +249,14 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 		const uint32_t cpA = pvA, cpB = pvB;
 		if (s + 1 < nT) {  // the next tile's rows are in flight across the analysis below
 			load_rows(tile + 1, r);
-			ent = ptab[(int)a.tile_orient[tile + 1] * PW + tid];
+			ent = ptab[(int)a.tiles.orient[tile + 1] * PW + tid];
 		}
 		stamp<STAMP>(st, 1);
 		uint32_t orall = cpA | cpB;
 #pragma unroll
 		for (int j = 0; j < 8; j++) orall |= dA[j] | dB[j];
 		const bool wide = SGN || __any((orall & 0xC000C000u) != 0);
+		bool any_diff = false;
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
 			const int k = h ? kB : kA;
@@ -269,35 +268,35 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 			const bool difficult = seg && chg >= 8u;                      // cluster.py:58
 			const int b = tile * 256 + k;
 			ssz[b] = (uint8_t)((16u + n2) | (difficult ? 0x80u : 0u));
-			// difficult blocks go to the slice's work list of the mask kernel (any order), one atomic per wave
-			const uint64_t bal = __ballot(difficult);
-			if (bal) {
-				uint32_t base = 0;
-				if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(a.dcount + sl, (uint32_t)__popcll(bal));
-				base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__ffsll((long long)bal) - 1);
-				if (difficult) {
-					a.dlist[(size_t)sl * NB + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)b | (chg + enter) << 24;  // cluster.py:110
-				}
-			}
+			if (difficult) gmask[b] = (uint64_t)(chg + enter);            // cluster.py:110; the mask kernel replaces it with the mask
+			any_diff |= difficult;
 		}
+		// tiles the mask kernel has to look at: listed once per slice (the workgroup's two waves may both ask)
+		if (__any(any_diff) && lane == 0 && atomicOr(a.tflag + (size_t)sl * NT + tile, 1u) == 0u)
+			a.tlist[(size_t)sl * NT + atomicAdd(a.tcount + sl, 1u)] = (uint32_t)tile;
 		stamp<STAMP>(st, 2);
 		if (s + 1 < nT) load_prev(tile + 1, ent, pvA, pvB);
 		stamp<STAMP>(st, 3);
 	}
+	if (STAMP) { st.acc[5] = st.rt0; st.acc[6] = __builtin_amdgcn_s_memrealtime(); }
 	stamp_store<STAMP>(st, stamps, blockIdx.x * 2 + wave);
 }
 
 // ---- K1b --------------------------------------------------------------------------------------------------
-// MQ workgroups of MW waves per slice take the slice's difficult blocks (listed by K1a, any order) round-robin, so that
-// the mask work is spread evenly whatever tiles it sits in.  For a difficult block i lane j fetches block i + j (four
-// 8-byte row segments, cache hits: K1a has just streamed them), puts it in traversal order and counts the positive
-// jumps of the interleaved order A0 B0 A1 B1 ... (cluster.py:131-153); lane 0 holds block A itself, whose terms go to
-// SGPRs.  The fetch of the next entry is in flight while this one is evaluated.
+// MQ workgroups (4 waves) per slice walk the slice's tiles that have difficult blocks (K1a lists them): few, long-lived
+// waves, because launching a wave costs ~2 ns chip-wide (measured: kernels of 32768 short waves take >= 65 us whatever
+// they do).  A tile's 256 blocks and the first 64 blocks of the next tile -- every candidate a difficult block of this tile can have -- are
+// fetched once (lane = traversal block: four 8-byte row segments, cache hits: K1a has just streamed them), put in
+// traversal order and kept in LDS (32 bytes per block).  The waves then take the tile's difficult blocks round-robin:
+// lane j compares block i + j with block i, whose terms go to SGPRs, and counts the positive jumps of the interleaved
+// order A0 B0 A1 B1 ... (cluster.py:131-153).
 constexpr int MW = 4, MQ = 8;          // waves per workgroup, workgroups per slice
-constexpr int K1B_BTAB = 0;            // TILE_MAX_ORIENT x 256 u32
-constexpr int K1B_TILE = K1B_BTAB + TILE_MAX_ORIENT * 1024;  // 256 u32: tile origin | orientation << 28
-constexpr int K1B_OTAB = K1B_TILE + 1024;
-constexpr int K1B_LDS = K1B_OTAB + 256;
+constexpr int K1B_DLIN = 0;            // 320 blocks x 32 bytes
+constexpr int K1B_BTAB = 320 * 32;
+constexpr int K1B_OTAB = K1B_BTAB;
+constexpr int K1B_LIST = K1B_OTAB + 256;   // 256 u16: block | cur << 8
+constexpr int K1B_MISC = K1B_LIST + 512;
+constexpr int K1B_LDS = K1B_MISC + 32;
 
 template <bool SGN, bool STAMP>
 __global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a, uint64_t *stamps)
@@ -305,102 +304,118 @@ __global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a, uint64_
 	Stamps st;
 	stamp_init<STAMP>(st);
 	__shared__ __attribute__((aligned(16))) uint8_t smem[K1B_LDS];
-	LDS(uint32_t) *btab = (LDS(uint32_t) *)(smem + K1B_BTAB);
-	LDS(uint32_t) *ltile = (LDS(uint32_t) *)(smem + K1B_TILE);
+	LDS(uint8_t) *dlin = (LDS(uint8_t) *)(smem + K1B_DLIN);
 	LDS(uint32_t) *otab = (LDS(uint32_t) *)(smem + K1B_OTAB);
+	LDS(uint16_t) *lst = (LDS(uint16_t) *)(smem + K1B_LIST);
+	LDS(uint32_t) *misc = (LDS(uint32_t) *)(smem + K1B_MISC);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
 	const int sl = blockIdx.x / MQ, q = blockIdx.x % MQ;
-	const int total = (int)a.dcount[sl];
-	const int first = q * MW + wave, stride = MQ * MW;
-	if (q * MW >= total) return;  // nothing for this workgroup (uniform)
-	const uint32_t *dlist = a.dlist + (size_t)sl * NB;
+	const int ntl = (int)a.tcount[sl];
+	if (q >= ntl) return;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	uint64_t *gmask = a.mask + (size_t)sl * NB;
 	const int pitch = a.row_pitch;
-	for (int i = tid; i < a.n_orient * 256; i += 64 * MW) btab[i] = a.btab[i];
-	for (int i = tid; i < NT; i += 64 * MW) ltile[i] = a.tile_org[i] | (uint32_t)a.tile_orient[i] << 28;
 	if (tid < 64) otab[tid] = a.otab[tid];
+	for (int ti = q; ti < ntl; ti += MQ) {
+	const int tile = (int)a.tlist[(size_t)sl * NT + ti];  // 32-bit entries: a wave-uniform read becomes a scalar (dword-aligned) load
+	const bool has_next = tile + 1 < NT;
+	const int to0 = a.tiles.orient[tile], to1 = has_next ? a.tiles.orient[tile + 1] : to0;
+	const uint32_t org0 = a.tiles.org[tile], org1 = has_next ? a.tiles.org[tile + 1] : org0;
+	// ---- this lane's block of the tile (and, for the first wave, of the next tile's first quarter)
+	const uint32_t bt0 = a.btab[to0 * 256 + tid];
+	const uint16_t *p0 = img + org0 + (bt0 & 0xFFFFFFu);
+	const uint2 r0 = *reinterpret_cast<const uint2 *>(p0), r1 = *reinterpret_cast<const uint2 *>(p0 + pitch);
+	const uint2 r2 = *reinterpret_cast<const uint2 *>(p0 + 2 * (size_t)pitch), r3 = *reinterpret_cast<const uint2 *>(p0 + 3 * (size_t)pitch);
+	uint32_t bt1 = 0;
+	uint2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
+	if (wave == 0 && has_next) {
+		bt1 = a.btab[to1 * 256 + lane];
+		const uint16_t *p1 = img + org1 + (bt1 & 0xFFFFFFu);
+		n0 = *reinterpret_cast<const uint2 *>(p1); n1 = *reinterpret_cast<const uint2 *>(p1 + pitch);
+		n2 = *reinterpret_cast<const uint2 *>(p1 + 2 * (size_t)pitch); n3 = *reinterpret_cast<const uint2 *>(p1 + 3 * (size_t)pitch);
+	}
+	// the tile's difficult blocks: one byte per lane; cur waits in the mask slot
+	const uint8_t sz = a.ssz[(size_t)sl * NB + tile * 256 + tid];
+	const bool diff = (sz & 0x80u) != 0;
+	uint32_t cur = 0;
+	if (diff) cur = (uint32_t)gmask[tile * 256 + tid];
+	const uint64_t bal = __ballot(diff);
+	if (lane == 0) misc[wave] = (uint32_t)__popcll(bal);
+	__syncthreads();
+	{
+		uint32_t d[8];
+		permute_block(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, (const LDS(uint32_t) *)otab + (bt0 >> 24) * 16, d);
+		*(LDS(u32x4) *)(dlin + tid * 32) = (u32x4){d[0], d[1], d[2], d[3]};
+		*(LDS(u32x4) *)(dlin + tid * 32 + 16) = (u32x4){d[4], d[5], d[6], d[7]};
+		if (wave == 0) {
+			if (has_next) permute_block(n0.x, n0.y, n1.x, n1.y, n2.x, n2.y, n3.x, n3.y, (const LDS(uint32_t) *)otab + (bt1 >> 24) * 16, d);
+			*(LDS(u32x4) *)(dlin + (256 + lane) * 32) = (u32x4){d[0], d[1], d[2], d[3]};
+			*(LDS(u32x4) *)(dlin + (256 + lane) * 32 + 16) = (u32x4){d[4], d[5], d[6], d[7]};
+		}
+		uint32_t pos = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+		for (int v = 0; v < MW; v++) if (v < wave) pos += misc[v];
+		if (diff) lst[pos] = (uint16_t)(tid | (cur << 8));
+	}
+	const int total = (int)(misc[0] + misc[1] + misc[2] + misc[3]);
 	stamp<STAMP>(st, 0);
 	__syncthreads();
 	stamp<STAMP>(st, 1);
-
-	struct Rows { uint2 r0, r1, r2, r3; uint32_t bt; };
-	// rows of candidate block (b + lane) of the slice; lanes without a candidate re-read block b
-	auto fetch = [&](int b, Rows &o, bool &valid) {
-		valid = lane >= 1 && b + lane < NB;
-		const int c = (lane == 0 || valid) ? b + lane : b;
-		const uint32_t tl = ltile[c >> 8];
-		o.bt = btab[(tl >> 28) * 256 + (c & 255)];
-		const uint16_t *p = img + (tl & 0x0FFFFFFFu) + (o.bt & 0xFFFFFFu);
-		o.r0 = *reinterpret_cast<const uint2 *>(p);
-		o.r1 = *reinterpret_cast<const uint2 *>(p + pitch);
-		o.r2 = *reinterpret_cast<const uint2 *>(p + 2 * (size_t)pitch);
-		o.r3 = *reinterpret_cast<const uint2 *>(p + 3 * (size_t)pitch);
-	};
-
-	// ---- this wave's entries: first + k * stride, 64 of them listed per round with one load
-	for (int e0 = first; e0 < total; e0 += 64 * stride) {
-		const int ne = min(64, (total - e0 + stride - 1) / stride);
-		uint32_t ents = 0;
-		if (lane < ne) ents = dlist[e0 + lane * stride];
-		Rows nx;
-		bool nvalid;
-		fetch((int)(__builtin_amdgcn_readlane((int)ents, 0) & 0xFFFFFF), nx, nvalid);
-		stamp<STAMP>(st, 2);
-		for (int e = 0; e < ne; e++) {
-			const Rows cu = nx;
-			const bool valid = nvalid;
-			const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)ents, e);
-			const int b = (int)(ent & 0xFFFFFFu);
-			const uint32_t cur = ent >> 24;
-			if (e + 1 < ne) fetch((int)(__builtin_amdgcn_readlane((int)ents, e + 1) & 0xFFFFFF), nx, nvalid);
-			uint32_t bw[8];
-			permute_block(cu.r0.x, cu.r0.y, cu.r1.x, cu.r1.y, cu.r2.x, cu.r2.y, cu.r3.x, cu.r3.y, (const LDS(uint32_t) *)otab + (cu.bt >> 24) * 16, bw);
-			uint32_t aw[8];
+	for (int e = wave; e < total; e += MW) {
+		const uint32_t ent = lst[e];
+		const int i = (int)(ent & 0xFFu);
+		const uint32_t ecur = ent >> 8;
+		const int b = tile * 256 + i;
+		const bool valid = lane >= 1 && b + lane < NB;
+		const int c = valid ? i + lane : i;
+		const LDS(u32x4) *ap = (const LDS(u32x4) *)(dlin + i * 32), *bp = (const LDS(u32x4) *)(dlin + c * 32);
+		const u32x4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+		const uint32_t bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+		const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+		uint32_t aw[8];
 #pragma unroll
-			for (int j = 0; j < 8; j++) aw[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw[j]);  // lane 0 = block A
-			uint32_t hi_or = 0;
+		for (int j = 0; j < 8; j++) aw[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)av[j]);  // block A is wave-uniform
+		uint32_t hi_or = 0;
 #pragma unroll
-			for (int j = 0; j < 8; j++) hi_or |= bw[j];
-			const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
-			uint32_t up;
-			if (small) {
-				// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences
-				// are exact: count the NEGATIVE results of B[t] - (A[t] + 65) and A[t+1] - (B[t] + 65).  A is
-				// wave-uniform: its terms are scalar (no carry between the halves below 0x4000); t = 15 has no
-				// successor: 0 - (B + 65) < 0
-				const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
-				uint32_t neg = 0;
+		for (int j = 0; j < 8; j++) hi_or |= bw[j] | aw[j];
+		const bool small = !SGN && !__any((hi_or & 0xC000C000u) != 0);
+		uint32_t up;
+		if (small) {
+			// up = #(B[t] - A[t] >= 65) + #(A[t+1] - B[t] >= 65); all values < 16384, so packed 16-bit differences
+			// are exact: count the NEGATIVE results of B[t] - (A[t] + 65) and A[t+1] - (B[t] + 65).  A's terms are
+			// scalar (no carry between the halves below 0x4000); t = 15 has no successor: 0 - (B + 65) < 0
+			const uint32_t FIFTEEN = 0x000F000Fu, K65 = 0x00410041u;
+			uint32_t neg = 0;
 #pragma unroll
-				for (int j = 0; j < 8; j++) {
-					const uint32_t a65 = aw[j] + K65;
-					const uint32_t an = (j < 7) ? ((aw[j] >> 16) | (aw[j + 1] << 16)) : (aw[7] >> 16);
-					neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[j], a65)));
-					neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(an, pk_add(bw[j], K65))));
-				}
-				up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
-			} else {
-				up = 0;
-				int bprev = 0;
-#pragma unroll
-				for (int t = 0; t < 16; t++) {
-					int av = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
-					if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
-					if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
-					up += (bv - av >= 65) ? 1u : 0u;
-					bprev = bv;
-				}
+			for (int j = 0; j < 8; j++) {
+				const uint32_t a65 = aw[j] + K65;
+				const uint32_t an = (j < 7) ? ((aw[j] >> 16) | (aw[j + 1] << 16)) : (aw[7] >> 16);
+				neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(bw[j], a65)));
+				neg = pk_add(neg, pk_lshr(FIFTEEN, pk_sub(an, pk_add(bw[j], K65))));
 			}
-			// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
-			const bool fit = valid && (b == 0 ? true : ((up + 1u) < (cur - 2u)));
-			const uint64_t mk = __ballot(fit);
-			if (lane == 0) gmask[b] = mk;
+			up = 32u - ((neg & 0xFFFFu) + (neg >> 16));
+		} else {
+			up = 0;
+			int bprev = 0;
+#pragma unroll
+			for (int t = 0; t < 16; t++) {
+				int avv = (int)((aw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
+				if (SGN) { avv = (int)(int16_t)avv; bv = (int)(int16_t)bv; }
+				if (t > 0) up += (avv - bprev >= 65) ? 1u : 0u;
+				up += (bv - avv >= 65) ? 1u : 0u;
+				bprev = bv;
+			}
 		}
-		stamp<STAMP>(st, 3);
+		// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 wraps: it always fits
+		const bool fit = valid && (b == 0 ? true : ((up + 1u) < (ecur - 2u)));
+		const uint64_t mk = __ballot(fit);
+		if (lane == 0) gmask[b] = mk;
 	}
-	if (STAMP) { st.acc[5] = st.rt0; st.acc[6] = __builtin_amdgcn_s_memrealtime(); }  // timeline instead of phases 5, 6
+	stamp<STAMP>(st, 2);
+	__syncthreads();  // the staged tile and the list are reused
+	}
+	if (STAMP) { st.acc[5] = st.rt0; st.acc[6] = __builtin_amdgcn_s_memrealtime(); }
 	stamp_store<STAMP>(st, stamps, blockIdx.x * MW + wave);
 }
 
@@ -410,8 +425,8 @@ constexpr int K2_CAP = 4096;                      // difficult-list records kept
 constexpr int K2_ROLE = 0;                        // PIPE_MAX_NB bytes
 constexpr int K2_IDX = PIPE_MAX_NB;               // K2_CAP u32
 constexpr int K2_MASK = K2_IDX + K2_CAP * 4;      // K2_CAP u64
-constexpr int K2_TSUM = K2_MASK + K2_CAP * 8;     // 256 i32 (sum of single sizes + corrections per tile)
-constexpr int K2_MISC = K2_TSUM + 256 * 4;
+constexpr int K2_TSUM = K2_MASK + K2_CAP * 8;     // 512 i32 (sum of single sizes + corrections per half tile)
+constexpr int K2_MISC = K2_TSUM + 512 * 4;
 constexpr int K2_LDS = K2_MISC + 128;
 
 __device__ __forceinline__ uint32_t wg_incl_scan256(uint32_t v, LDS(uint32_t) *scratch, int tid, uint32_t &total)
@@ -455,7 +470,7 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 	auto mask_of = [&](uint32_t e, uint32_t i) -> uint64_t { uint64_t v; if (e < K2_CAP) v = l_mask[e]; else v = gmask[i]; return v; };
 
 	for (int i = tid; i < NB / 16; i += K2T) *(LDS(u32x4) *)(role + i * 16) = (u32x4){0, 0, 0, 0};
-	for (int i = tid; i < NT; i += K2T) tsum[i] = 0;
+	for (int i = tid; i < 2 * NT; i += K2T) tsum[i] = 0;
 	if (tid < 8) misc[tid] = 0;
 	__syncthreads();
 	stamp<STAMP>(st, 0);
@@ -473,7 +488,7 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 			cnt += (uint32_t)__popc(w[q] & 0x80808080u);
 			sum = __builtin_amdgcn_udot4(w[q] & 0x7F7F7F7Fu, 0x01010101u, sum, false);
 		}
-		lds_add(&tsum[c >> 4], (int32_t)sum);
+		lds_add(&tsum[c >> 3], (int32_t)sum);
 	}
 	uint32_t ndiff;
 	uint32_t pos = wg_incl_scan256(cnt, misc, tid, ndiff) - cnt;
@@ -606,15 +621,15 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 #pragma unroll
 			for (int t = 0; t < 16; t++) { put(va[t] - prev); put(vb[t] - va[t]); prev = vb[t]; }
 			spec[i] = (slot << 8) | (uint32_t)n;
-			lds_add(&tsum[i >> 8], n - sz_i);
-			lds_add(&tsum[p >> 8], -sz_p);
+			lds_add(&tsum[i >> 7], n - sz_i);
+			lds_add(&tsum[p >> 7], -sz_p);
 			// blocks after the leader and after the partner, if emitted alone
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
 				if (!follow[h]) continue;
 				spec[bs[h]] = (uint32_t)ftp[h];
 				const int corr = (int)tok_two(fv0[h] - ftp[h]) - (int)tok_two(fv0[h] - fdp[h]);
-				if (corr) lds_add(&tsum[bs[h] >> 8], corr);
+				if (corr) lds_add(&tsum[bs[h] >> 7], corr);
 			}
 		}
 	}
@@ -630,13 +645,13 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 		*reinterpret_cast<u32x4 *>(groles + (size_t)i * 16) = v;
 		if (oroles) *reinterpret_cast<u32x4 *>(oroles + (size_t)i * 16) = v;
 	}
-	uint32_t *toff = a.toff + (size_t)sl * (NT + 1);
+	uint32_t *toff = a.toff + (size_t)sl * (2 * NT + 1);  // payload offset of every half tile (128 blocks)
 	uint32_t total;
 	{
-		const uint32_t mine = tid < NT ? (uint32_t)tsum[tid] : 0u;
-		const uint32_t inc = wg_incl_scan256(mine, misc, tid, total);
-		if (tid < NT) toff[tid] = inc - mine;
-		if (tid == 0) toff[NT] = total;
+		const uint32_t m0 = tid < NT ? (uint32_t)tsum[2 * tid] : 0u, m1 = tid < NT ? (uint32_t)tsum[2 * tid + 1] : 0u;
+		const uint32_t inc = wg_incl_scan256(m0 + m1, misc, tid, total);
+		if (tid < NT) { toff[2 * tid] = inc - m0 - m1; toff[2 * tid + 1] = inc - m1; }
+		if (tid == 0) toff[2 * NT] = total;
 	}
 	if (tid == 0) {
 		const uint32_t njump = misc[4];
@@ -655,14 +670,22 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------
-constexpr int K3_STG = 0;                         // STG_BYTES
-constexpr int K3_TTAB = STG_BYTES;                // 16 entries x 128 bytes (the index arrives as mask-sum << 7)
-constexpr int K3_OTAB = K3_TTAB + 2048;           // 256
-constexpr int K3_SZL = K3_OTAB + 256;             // 256 token sizes of the tile's blocks, traversal order
-constexpr int K3_OFFL = K3_SZL + 256;             // 2 x 256 u16: their offsets, one copy per wave
-constexpr int K3_PAIR = K3_OFFL + 1024;           // PAIR_CAP x 8
-constexpr int K3_MISC = K3_PAIR + PAIR_CAP * 8;   // [2] pair count, [3] status
-constexpr int K3_LDS = K3_MISC + 64;
+// Measured (tools/sweep_pipe.py, CCT_K3_EXTRA_LDS): whatever a workgroup declares, about 96 KB of LDS per CU are in use at a
+// time, so LDS per wave decides the residency.  The payload image therefore holds what real slices need (a half tile of
+// 2048 pixels at up to 1.45 bytes per pixel); a half tile that needs more (up to 6.2 KB: dense meshes of noise) is written
+// byte by byte to HBM instead (emit_block_bytes): exact, slow, rare.
+constexpr int HSTG_BYTES = 3072;                  // payload image of a half tile
+constexpr int HSTG_FIT = HSTG_BYTES - 32;         // head + tokens + EOF must stay below (the ORs touch up to 11 bytes more)
+constexpr int K3_STG = 0;                         // HSTG_BYTES
+constexpr int K3_TTAB = HSTG_BYTES;               // 16 entries x 16 bytes
+constexpr int K3_OTAB = K3_TTAB + 256;            // 256
+constexpr int K3_SZL = K3_OTAB + 256;             // 128 token sizes of the half tile's blocks, traversal order
+constexpr int K3_OFFL = K3_SZL + 128;             // 128 u16: their offsets
+constexpr int K3_PAIR = K3_OFFL + 256;            // 128 x 8: leaders (offset, record) -- shares its bytes with ...
+constexpr int K3_SPEC = K3_PAIR;                  // ... 128 u32 spec words, which are in registers before the first leader is listed
+constexpr int K3_LAST = K3_PAIR + 128 * 8;        // 129 u16
+constexpr int K3_ROLE = K3_LAST + 272 + 1;        // 130 bytes from an ODD address: [1 + 2 lane] pairs are then 2-byte aligned
+constexpr int K3_LDS = K3_ROLE + 143;
 
 // two-byte masks of the four 4-pixel groups of a block: bit 7 of byte p of m[g] <=> pixel 4g+p takes two bytes
 __device__ __forceinline__ uint32_t group_masks(const uint32_t x[8], uint32_t m[4])
@@ -708,7 +731,7 @@ __device__ __forceinline__ void emit_block(const uint32_t x[8], const uint32_t m
 		const uint32_t P = (pd & 0x7F7F7F7Fu) | (pd & m[g]);                         // short: 7 bits; full: second byte
 		const uint32_t X = (perm(xb, xa, 0x07050301u) & 0x0F0F0F0Fu) | 0xE0E0E0E0u;  // full: first byte
 		const uint32_t ti = __builtin_amdgcn_udot4(m[g], 0x08040201u, 0u, false);    // mask as 4 bits << 7
-		const u32x4 te = *(const LDS(u32x4) *)(ttab + ti);
+		const u32x4 te = *(const LDS(u32x4) *)(ttab + (ti >> 3));
 		const uint32_t lo = perm(X, P, te.x), hi = perm(X, P, te.y);
 		// shift the 4..8 bytes to the byte phase of o and merge
 		const uint32_t s8 = (o & 3u) * 8u;
@@ -722,8 +745,27 @@ __device__ __forceinline__ void emit_block(const uint32_t x[8], const uint32_t m
 	}
 }
 
+// tokens of one block straight to HBM, one byte at a time (oversized half tiles only)
+__device__ __forceinline__ void emit_block_bytes(const uint32_t d[8], uint32_t pv, uint8_t *out)
+{
+	int pu = (int)(pv & 0xFFFFu);
+	for (int i = 0; i < 16; i++) {
+		const int v = px16(d, i), dlt = v - pu;
+		if (tok_two(dlt)) { *out++ = (uint8_t)(0xE0 | ((dlt >> 8) & 0x0F)); *out++ = (uint8_t)(dlt & 0xFF); }
+		else *out++ = (uint8_t)(dlt & 0x7F);
+		pu = v;
+	}
+}
+
+// One wave per half tile (128 traversal blocks = a 64x32 or a 32x64 pixel region; lane = a pair of blocks as before).
+// No workgroup barrier: sizes, offsets and the payload image are private to the wave, LDS accesses of a wave execute in
+// order, and wave_fence() keeps the compiler from moving them across the phase boundaries.  Every global load is
+// issued up front: pixel rows, the half tile's roles and spec words (coalesced, into LDS) and the one pixel before the
+// half tile; pixels before the other blocks are exchanged through LDS after the permute.
+__device__ __forceinline__ void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <bool STAMP>
-__global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a, uint64_t *stamps)
+__global__ void __launch_bounds__(64) pipe_pack_kernel(PipeArgs a, uint64_t *stamps)
 {
 	Stamps st;
 	stamp_init<STAMP>(st);
@@ -734,59 +776,70 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a, uint64_t *sta
 	LDS(uint8_t) *szl = (LDS(uint8_t) *)(smem + K3_SZL);
 	LDS(uint16_t) *offl = (LDS(uint16_t) *)(smem + K3_OFFL);
 	LDS(uint32_t) *pairs = (LDS(uint32_t) *)(smem + K3_PAIR);
-	LDS(uint32_t) *misc = (LDS(uint32_t) *)(smem + K3_MISC);
+	LDS(uint8_t) *rl = (LDS(uint8_t) *)(smem + K3_ROLE);       // [0] role of the block before the half tile, [1 + k] role of block k
+	LDS(uint32_t) *specl = (LDS(uint32_t) *)(smem + K3_SPEC);
+	LDS(uint16_t) *lastpx = (LDS(uint16_t) *)(smem + K3_LAST);  // [0] pixel before the half tile, [1 + k] last pixel of block k
 
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int lane = threadIdx.x;
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N;
-	const int sl = blockIdx.x / NT, tile = blockIdx.x % NT;
+	const int NH = 2 * NT;
+	const int sl = blockIdx.x / NH, ht = blockIdx.x % NH;
+	const int tile = ht >> 1, half = ht & 1;
+	const int hb = ht * 128;  // first block of the half tile in the slice
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	const int pitch = a.row_pitch;
-	const int to = a.tile_orient[tile];
+	const int to = a.tiles.orient[tile];
 
-	// ---- loads first: the lane's table entry, pixel rows, then what depends on the entry
-	const u32x4 ent = reinterpret_cast<const u32x4 *>(a.ptab)[to * PW + tid];
-	const int by = tid >> 3, bxp = tid & 7;
-	const uint32_t org = a.tile_org[tile];
-	const uint16_t *p = img + org + (size_t)(by * 4) * pitch + bxp * 8;
+	// ---- every global load, issued together
+	const u32x4 ent = reinterpret_cast<const u32x4 *>(a.ptab2)[(to * 2 + half) * 64 + lane];
+	const uint32_t org = a.tiles.org[tile];
+	uint32_t before_addr = 0;  // the pixel before the half tile (none: the slice starts from pixel value 0, core.py:278)
+	if (half) before_addr = org + a.tiles.mid[to];
+	else if (tile > 0) before_addr = a.tiles.org[tile - 1] + a.tiles.last[a.tiles.orient[tile - 1]];
+	const uint32_t *toff = a.toff + (size_t)sl * (NH + 1);
+	const uint32_t off_t = toff[ht], off_n = toff[ht + 1];
+	const uint8_t *roles = a.roles + (size_t)sl * NB + hb;
+	const uint32_t *spec = a.spec + (size_t)sl * NB + hb;
+	const uint32_t role2 = *reinterpret_cast<const uint16_t *>(roles + 2 * lane);
+	const uint2 spec2 = *reinterpret_cast<const uint2 *>(spec + 2 * lane);
+	uint32_t edge = 0;  // lane 0: role of the block before the half tile | pixel before the half tile << 16
+	if (lane == 0) edge = (hb > 0 ? (uint32_t)roles[-1] : 0u) | (ht > 0 ? (uint32_t)img[before_addr] << 16 : 0u);
+	const uint32_t geom = a.tiles.geom[to * 2 + half];
+	const uint32_t reg_off = (geom & 1u) ? (uint32_t)((lane >> 2) * 4 * pitch) + ((geom >> 8) + (uint32_t)(lane & 3)) * 8u
+	                                     : ((geom >> 8) + (uint32_t)(lane >> 3)) * 4u * (uint32_t)pitch + (uint32_t)(lane & 7) * 8u;
+	const uint16_t *p = img + org + reg_off;
 	u32x4 r[4];
 #pragma unroll
 	for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
-	const uint32_t *toff = a.toff + (size_t)sl * (NT + 1);
-	const uint32_t off_t = toff[tile], off_n = toff[tile + 1];
-	const int kA = (int)(ent.x & 0xFFu), kB = (int)((ent.x >> 16) & 0xFFu);
-	const int bA = tile * 256 + kA, bB = tile * 256 + kB;
-	const uint8_t *roles = a.roles + (size_t)sl * NB;
-	const uint32_t roleA = roles[bA], roleB = roles[bB];
-	const uint32_t rolepA = bA > 0 ? roles[bA - 1] : 0u, rolepB = bB > 0 ? roles[bB - 1] : 0u;
-	const uint32_t porg = tile > 0 ? a.tile_org[tile - 1] + a.tile_last[a.tile_orient[tile - 1]] : 0u;
-	uint32_t pvA = img[ent.y != 0xFFFFFFFFu ? org + ent.y : porg];
-	uint32_t pvB = img[ent.z != 0xFFFFFFFFu ? org + ent.z : porg];
-	if (bA == 0) pvA = 0;  // the slice starts from pixel value 0 (core.py:278)
-	if (bB == 0) pvB = 0;
-	// special blocks: leaders carry their record and size, blocks after a meshed block their predecessor pixel
-	const uint32_t *spec = a.spec + (size_t)sl * NB;
-	const bool leadA = roleA >= 1 && roleA <= 63, leadB = roleB >= 1 && roleB <= 63;
-	const bool succA = roleA == 0 && rolepA != 0, succB = roleB == 0 && rolepB != 0;
-	uint32_t spA = 0, spB = 0;
-	if (leadA || succA) spA = spec[bA];
-	if (leadB || succB) spB = spec[bB];
 
 	// ---- tables and the zeroed payload image
-	if (tid < 64) otab[tid] = a.otab[tid];
-	if (tid < 16) *(LDS(u32x4) *)(ttab + tid * 128) = reinterpret_cast<const u32x4 *>(a.ttab)[tid];
-	for (int i = tid; i < STG_BYTES / 16; i += PW) *(LDS(u32x4) *)(stg + i * 16) = (u32x4){0, 0, 0, 0};
-	if (tid < 4) misc[tid] = 0;
+	otab[lane] = a.otab[lane];
+	if (lane < 16) *(LDS(u32x4) *)(ttab + lane * 16) = reinterpret_cast<const u32x4 *>(a.ttab)[lane];
+	for (int i = lane; i < HSTG_BYTES / 16; i += 64) *(LDS(u32x4) *)(stg + i * 16) = (u32x4){0, 0, 0, 0};
+	*(LDS(uint16_t) *)(rl + 1 + 2 * lane) = (uint16_t)role2;  // rl[1 + 2 lane], rl[2 + 2 lane] at an even address: rl starts odd
+	specl[2 * lane] = spec2.x;
+	specl[2 * lane + 1] = spec2.y;
+	if (lane == 0) { rl[0] = (uint8_t)edge; lastpx[0] = (uint16_t)(edge >> 16); }
+	wave_fence();
 	stamp<STAMP>(st, 0);
-	__syncthreads();
-	stamp<STAMP>(st, 1);
+	const uint32_t dbg = a.e.dbg_skip;
+	if (dbg & 4u) { if ((r[0].x ^ r[1].y ^ r[2].z ^ r[3].w ^ role2 ^ spec2.x) == 0x12345678u) a.e.status[sl] = 1; return; }
 
-	// ---- traversal order inside the lane's two blocks, deltas, token sizes
+	// ---- traversal order inside the lane's two blocks; pixels before them through LDS
+	const int hk = half * 128;
+	const int kA = (int)(ent.x & 0xFFu) - hk, kB = (int)((ent.x >> 16) & 0xFFu) - hk;  // block inside the half tile
 	uint32_t dA[8], dB[8], xA[8], xB[8], mA[4], mB[4];
 	permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((ent.x >> 8) & 3u) * 16, dA);
 	permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((ent.x >> 24) & 3u) * 16, dB);
-	if (succA) pvA = spA;
-	if (succB) pvB = spB;
+	lastpx[1 + kA] = (uint16_t)(dA[7] >> 16);
+	lastpx[1 + kB] = (uint16_t)(dB[7] >> 16);
+	wave_fence();
+	const uint32_t roleA = rl[1 + kA], roleB = rl[1 + kB], rolepA = rl[kA], rolepB = rl[kB];
+	// special blocks: leaders carry their record and size, blocks after a meshed block their predecessor pixel
+	const bool leadA = roleA >= 1 && roleA <= 63, leadB = roleB >= 1 && roleB <= 63;
+	const bool succA = roleA == 0 && rolepA != 0, succB = roleB == 0 && rolepB != 0;
+	const uint32_t spA = specl[kA], spB = specl[kB];
+	const uint32_t pvA = succA ? spA : lastpx[kA], pvB = succB ? spB : lastpx[kB];
 	deltas16(dA, pvA, xA);
 	deltas16(dB, pvB, xB);
 	uint32_t orall = pvA | pvB;
@@ -817,71 +870,96 @@ __global__ void __launch_bounds__(PW) pipe_pack_kernel(PipeArgs a, uint64_t *sta
 	const uint32_t szB = roleB == 0 ? 16u + n2B : (leadB ? (spB & 0xFFu) : 0u);
 	szl[kA] = (uint8_t)szA;
 	szl[kB] = (uint8_t)szB;
-	stamp<STAMP>(st, 2);
-	__syncthreads();
-	stamp<STAMP>(st, 3);
-	// ---- offsets: every wave scans the 256 sizes for itself (no second barrier), four blocks per lane
+	wave_fence();
+	stamp<STAMP>(st, 1);
+	// ---- offsets: scan of the 128 sizes, two blocks per lane
 	uint32_t tot;
 	{
-		const uint32_t v = *(const LDS(uint32_t) *)(szl + lane * 4);
-		const uint32_t s0 = v & 0xFFu, s1 = (v >> 8) & 0xFFu, s2 = (v >> 16) & 0xFFu, s3 = v >> 24;
-		const uint32_t sum4 = s0 + s1 + s2 + s3;
-		const uint32_t inc = wave_incl_scan(sum4);
+		const uint32_t v = *(const LDS(uint16_t) *)(szl + lane * 2);
+		const uint32_t s0 = v & 0xFFu, s1 = v >> 8;
+		const uint32_t inc = wave_incl_scan(s0 + s1);
 		tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-		const uint32_t e0 = inc - sum4, e1 = e0 + s0, e2 = e1 + s1, e3 = e2 + s2;
-		typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-		*(LDS(u32x2) *)(offl + wave * 256 + lane * 4) = (u32x2){e0 | (e1 << 16), e2 | (e3 << 16)};
+		const uint32_t e0 = inc - s0 - s1;
+		*(LDS(uint32_t) *)(offl + lane * 2) = e0 | ((e0 + s0) << 16);
 	}
+	wave_fence();
 	const uint32_t head = off_t & 15u;
-	const uint32_t oA = head + offl[wave * 256 + kA], oB = head + offl[wave * 256 + kB];
-	stamp<STAMP>(st, 4);
+	const uint32_t oA = head + offl[kA], oB = head + offl[kB];
+	stamp<STAMP>(st, 2);
 
-	// ---- tokens into the payload image
-	if (roleA == 0) emit_block(xA, mA, oA, stg, ttab);
-	if (roleB == 0) emit_block(xB, mB, oB, stg, ttab);
-	if (leadA) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = oA; pairs[2 * e + 1] = spA; }
-	if (leadB) { const uint32_t e = lds_add(&misc[2], 1u); pairs[2 * e] = oB; pairs[2 * e + 1] = spB; }
+	const bool last = ht == NH - 1;
 	uint32_t stat = q7 ? CCT_ST_Q7 : 0u;
-	if (tid == 0 && tot != off_n - off_t) stat |= CCT_ST_INTERNAL;
-	if (stat) lds_or(&misc[3], stat);
-	stamp<STAMP>(st, 5);
-	__syncthreads();
-	// ---- meshed pairs: K2 left their bytes in HBM records
-	const uint32_t npair = misc[2];
-	if (npair) {
-		const uint8_t *rec = a.pairrec + (size_t)sl * (NB / 2) * PIPE_PAIR_REC;
-		for (uint32_t e = wave; e < npair; e += 2) {
-			const uint32_t o = pairs[2 * e], sp = pairs[2 * e + 1];
-			const uint32_t n = sp & 0xFFu;
-			const uint8_t *src = rec + (size_t)(sp >> 8) * PIPE_PAIR_REC;
-			for (uint32_t j = lane; j < n; j += 64) stg[o + j] = src[j];
+	if (tot != off_n - off_t) stat |= CCT_ST_INTERNAL;
+	if (head + tot + 1u > (uint32_t)HSTG_FIT) {
+		// ---- oversized half tile: every lane writes its blocks (and its pair records) byte by byte
+		const uint32_t end = tot + ((last && a.e.eof >= 0) ? 1u : 0u);
+		const bool room = (size_t)off_t + ((end + 15u) & ~15u) + 16u <= a.e.stride;
+		uint8_t *out = a.e.payload + (size_t)sl * a.e.stride + off_t;
+		if (room) {
+			const uint8_t *rec = a.pairrec + (size_t)sl * (NB / 2) * PIPE_PAIR_REC;
+			if (roleA == 0) emit_block_bytes(dA, pvA, out + (oA - head));
+			if (roleB == 0) emit_block_bytes(dB, pvB, out + (oB - head));
+			if (leadA) { const uint8_t *src = rec + (size_t)(spA >> 8) * PIPE_PAIR_REC; for (uint32_t j = 0; j < (spA & 0xFFu); j++) out[oA - head + j] = src[j]; }
+			if (leadB) { const uint8_t *src = rec + (size_t)(spB >> 8) * PIPE_PAIR_REC; for (uint32_t j = 0; j < (spB & 0xFFu); j++) out[oB - head + j] = src[j]; }
+			if (last && lane < 16) {  // EOF (core.py:329-330) and the zero padding of the slice's last 16 bytes
+				const uint32_t i = tot + (uint32_t)lane;
+				if (lane == 0 && a.e.eof >= 0) out[i] = (uint8_t)a.e.eof;
+				else if (i >= end && ((size_t)off_t + i) < (((size_t)off_t + end + 15u) & ~(size_t)15u)) out[i] = 0;
+			}
+		} else stat |= CCT_ST_CAP;
+		if (__any(stat != 0)) { if (stat) atomicOr(a.e.status + sl, stat); }
+		stamp_store<STAMP>(st, stamps, blockIdx.x);
+		return;
+	}
+	// ---- tokens into the payload image
+	if (!(dbg & 2u)) {
+		if (roleA == 0) emit_block(xA, mA, oA, stg, ttab);
+		if (roleB == 0) emit_block(xB, mB, oB, stg, ttab);
+	}
+	// ---- meshed pairs: K2 left their bytes in HBM records; the wave copies them one after the other
+	{
+		const uint64_t lbA = __ballot(leadA), lbB = __ballot(leadB);
+		const uint32_t nA = (uint32_t)__popcll(lbA);
+		const uint64_t below = (1ull << lane) - 1ull;
+		if (leadA) { const uint32_t e = (uint32_t)__popcll(lbA & below); pairs[2 * e] = oA; pairs[2 * e + 1] = spA; }
+		if (leadB) { const uint32_t e = nA + (uint32_t)__popcll(lbB & below); pairs[2 * e] = oB; pairs[2 * e + 1] = spB; }
+		const uint32_t npair = nA + (uint32_t)__popcll(lbB);
+		wave_fence();  // the token ORs and the list are in LDS before record bytes are stored beside them
+		if (npair) {
+			const uint8_t *rec = a.pairrec + (size_t)sl * (NB / 2) * PIPE_PAIR_REC;
+			for (uint32_t e = 0; e < npair; e++) {
+				const uint32_t o = pairs[2 * e], sp = pairs[2 * e + 1];
+				const uint32_t n = sp & 0xFFu;
+				const uint8_t *src = rec + (size_t)(sp >> 8) * PIPE_PAIR_REC;
+				for (uint32_t j = lane; j < n; j += 64) stg[o + j] = src[j];
+			}
 		}
 	}
-	if (tile == NT - 1 && a.e.eof >= 0 && tid == 0) stg[head + tot] = (uint8_t)a.e.eof;  // core.py:329-330
-	if (npair || tile == NT - 1) __syncthreads();
-	stamp<STAMP>(st, 6);
-	// ---- flush: whole 16-byte chunks with one store, the two ends shared with the neighbouring tiles byte by byte
+	if (last && a.e.eof >= 0 && lane == 0) stg[head + tot] = (uint8_t)a.e.eof;  // core.py:329-330
+	wave_fence();
+	stamp<STAMP>(st, 3);
+	// ---- flush: whole 16-byte chunks with one store, the two ends shared with the neighbouring half tiles byte by byte
 	{
-		const bool last = tile == NT - 1;
 		const uint32_t end = head + tot + ((last && a.e.eof >= 0) ? 1u : 0u);
 		const size_t base = (size_t)(off_t & ~15u);
 		const bool room = base + ((end + 15u) & ~15u) <= a.e.stride;
 		uint8_t *out = a.e.payload + (size_t)sl * a.e.stride + base;
 		const uint32_t c_first = head ? 1u : 0u;                        // chunk 0 is partial when head > 0
-		const uint32_t c_end = last ? (end + 15u) / 16u : end / 16u;    // the last tile owns its padding
-		if (room) {
-			for (uint32_t c = c_first + tid; c < c_end; c += PW)
+		const uint32_t c_end = last ? (end + 15u) / 16u : end / 16u;    // the last half tile owns its padding
+		if (room && !(dbg & 1u)) {
+			for (uint32_t c = c_first + lane; c < c_end; c += 64)
 				*reinterpret_cast<u32x4 *>(out + (size_t)c * 16) = *(const LDS(u32x4) *)(stg + c * 16);
-			if (head && tid < 16 && (uint32_t)tid >= head && (uint32_t)tid < end) out[tid] = stg[tid];
-			if (!last && tid >= 16 && tid < 32) {
-				const uint32_t i = c_end * 16u + (uint32_t)(tid - 16);
+			if (head && lane < 16 && (uint32_t)lane >= head && (uint32_t)lane < end) out[lane] = stg[lane];
+			if (!last && lane >= 16 && lane < 32) {
+				const uint32_t i = c_end * 16u + (uint32_t)(lane - 16);
 				if (i < end && (i >= 16u || !head)) out[i] = stg[i];
 			}
-		}
-		if (tid == 0 && misc[3]) atomicOr(a.e.status + sl, misc[3] | (room ? 0u : CCT_ST_CAP));
+		} else stat |= CCT_ST_CAP;
 	}
-	stamp<STAMP>(st, 6);
-	stamp_store<STAMP>(st, stamps, blockIdx.x * 2 + wave);
+	if (__any(stat != 0)) { if (stat) atomicOr(a.e.status + sl, stat); }
+	stamp<STAMP>(st, 4);
+	if (STAMP) { st.acc[5] = st.rt0; st.acc[6] = __builtin_amdgcn_s_memrealtime(); }
+	stamp_store<STAMP>(st, stamps, blockIdx.x);
 }
 
 }  // namespace
@@ -900,6 +978,27 @@ static void report_stamps(const char *name, const uint64_t *d_buf, size_t nslots
 	fprintf(stderr, "\n");
 }
 
+static void report_timeline(const char *name, const uint64_t *d_buf, size_t nslots)
+{
+	std::vector<uint64_t> h(nslots * 8);
+	if (hipMemcpy(h.data(), d_buf, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+	uint64_t t0 = ~0ull;
+	for (size_t i = 0; i < nslots; i++) if (h[i * 8 + 5]) t0 = std::min(t0, h[i * 8 + 5]);
+	std::vector<double> st_, en_, lf_;
+	double life = 0;
+	for (size_t i = 0; i < nslots; i++) {
+		if (!h[i * 8 + 5]) continue;  // a wave that left before its first stamp
+		st_.push_back((h[i * 8 + 5] - t0) * 0.01); en_.push_back((h[i * 8 + 6] - t0) * 0.01);
+		lf_.push_back(en_.back() - st_.back()); life += lf_.back();
+	}
+	if (st_.empty()) return;
+	std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end()); std::sort(lf_.begin(), lf_.end());
+	const size_t m = st_.size();
+	fprintf(stderr, "[timeline] %s: life (us) p50 %.1f p90 %.1f p99 %.1f max %.1f\n", name, lf_[m / 2], lf_[m * 9 / 10], lf_[m * 99 / 100], lf_[m - 1]);
+	fprintf(stderr, "[timeline] %s: %zu waves, mean life %.2f us, mean concurrency %.0f waves | starts (us) p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f | ends p0 %.1f p50 %.1f p100 %.1f\n",
+	        name, m, life / m, life / en_[m - 1], st_[0], st_[m / 4], st_[m / 2], st_[3 * m / 4], st_[m - 1], en_[0], en_[m / 2], en_[m - 1]);
+}
+
 hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const PipeTune *tune)
 {
 	const int NT = pa.n_tiles;
@@ -912,23 +1011,23 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 	uint64_t *d_st = nullptr;
 	const size_t slots1 = (size_t)n * wps * 2, slots3 = (size_t)n * NT * 2;
 	if (stamps_on) {
-		if (hipMalloc(&d_st, std::max(std::max(slots1, slots3), (size_t)n * MQ * MW) * 64) != hipSuccess) return hipErrorOutOfMemory;
-		(void)hipMemset(d_st, 0, std::max(std::max(slots1, slots3), (size_t)n * MQ * MW) * 64);
+		if (hipMalloc(&d_st, std::max(std::max(slots1, slots3), (size_t)n * NT * MW) * 64) != hipSuccess) return hipErrorOutOfMemory;
+		(void)hipMemset(d_st, 0, std::max(std::max(slots1, slots3), (size_t)n * NT * MW) * 64);
 	}
 	if (stamps_on) {
 		int b1 = 0, b2 = 0, b3 = 0, b4 = 0;
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, (pipe_analyse_kernel<false, false>), PW, 0);
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (pipe_masks_kernel<false, false>), 64 * MW, 0);
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, pipe_resolve_kernel<false>, K2T, K2_LDS);
-		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, pipe_pack_kernel<false>, PW, 0);
-		fprintf(stderr, "[occupancy API] workgroups per CU: analyse %d (x2 waves)  masks %d (x%d waves)  resolve %d  pack %d (x2 waves)\n", b1, b2, MW, b3, b4);
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, pipe_pack_kernel<false>, 64, 0);
+		fprintf(stderr, "[occupancy API] workgroups per CU: analyse %d (x2 waves)  masks %d (x%d waves)  resolve %d  pack %d (x1 wave)\n", b1, b2, MW, b3, b4);
 	}
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	const bool timing = tune && tune->times_us;
 	if (timing) for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return hipErrorUnknown;
 	if (timing) (void)hipEventRecord(ev[0], s);
 	{
-		hipError_t e0 = hipMemsetAsync(pa.dcount, 0, (size_t)n * sizeof(uint32_t), s);
+		hipError_t e0 = hipMemsetAsync(pa.tflag, 0, (size_t)n * (NT + 1) * sizeof(uint32_t), s);  // flags, then the per-slice counts
 		if (e0 != hipSuccess) return e0;
 	}
 	if (stamps_on) {
@@ -937,6 +1036,7 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 		(void)hipStreamSynchronize(s);
 		static const char *const ph1[8] = {"setup", "perm+prefetch", "analysis", "prev-px", nullptr, nullptr, nullptr, nullptr};
 		report_stamps("K1a analyse", d_st, slots1, ph1);
+		report_timeline("K1a analyse", d_st, slots1);
 	} else if (sg) hipLaunchKernelGGL((pipe_analyse_kernel<true, false>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, (uint64_t *)nullptr);
 	else hipLaunchKernelGGL((pipe_analyse_kernel<false, false>), dim3(n * wps), dim3(PW), 0, s, pa, tpw, (uint64_t *)nullptr);
 	hipError_t e = hipGetLastError();
@@ -947,20 +1047,9 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 			(void)hipMemsetAsync(d_st, 0, (size_t)n * MQ * MW * 64, s);
 			hipLaunchKernelGGL((pipe_masks_kernel<false, true>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, d_st);
 			(void)hipStreamSynchronize(s);
-			static const char *const ph[8] = {"tables", "sync", "list+first fetch", "entries", nullptr, nullptr, nullptr, nullptr};
+			static const char *const ph[8] = {"fetch+stage", "sync", "entries", nullptr, nullptr, nullptr, nullptr, nullptr};
 			report_stamps("K1b masks", d_st, (size_t)n * MQ * MW, ph);
-			{
-				std::vector<uint64_t> h((size_t)n * MQ * MW * 8);
-				(void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
-				uint64_t t0 = ~0ull, t1 = 0;
-				for (size_t i = 0; i < h.size() / 8; i++) { t0 = std::min(t0, h[i * 8 + 5]); t1 = std::max(t1, h[i * 8 + 6]); }
-				std::vector<double> st_(h.size() / 8), en_(h.size() / 8);
-				for (size_t i = 0; i < st_.size(); i++) { st_[i] = (h[i * 8 + 5] - t0) * 0.01; en_[i] = (h[i * 8 + 6] - t0) * 0.01; }
-				std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end());
-				const size_t m = st_.size();
-				fprintf(stderr, "[timeline] K1b: wave starts (us) p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f | ends p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f\n",
-				        st_[0], st_[m / 4], st_[m / 2], st_[3 * m / 4], st_[m - 1], en_[0], en_[m / 4], en_[m / 2], en_[3 * m / 4], en_[m - 1]);
-			}
+			report_timeline("K1b masks", d_st, (size_t)n * MQ * MW);
 		} else if (sg) hipLaunchKernelGGL((pipe_masks_kernel<true, false>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, (uint64_t *)nullptr);
 		else hipLaunchKernelGGL((pipe_masks_kernel<false, false>), dim3(n * MQ), dim3(64 * MW), 0, s, pa, (uint64_t *)nullptr);
 		e = hipGetLastError();
@@ -987,12 +1076,13 @@ hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const Pi
 	if (timing) (void)hipEventRecord(ev[3], s);
 	if (stamps_on) {
 		(void)hipMemsetAsync(d_st, 0, slots3 * 64, s);
-		hipLaunchKernelGGL(pipe_pack_kernel<true>, dim3(n * NT), dim3(PW), 0, s, pa, d_st);
+		hipLaunchKernelGGL(pipe_pack_kernel<true>, dim3(n * NT * 2), dim3(64), getenv("CCT_K3_EXTRA_LDS") ? atoi(getenv("CCT_K3_EXTRA_LDS")) : 0, s, pa, d_st);
 		(void)hipStreamSynchronize(s);
-		static const char *const ph3[8] = {"loads+tables", "sync", "perm+sizes", "sync", "scan+offsets", "emit", "sync+pairs+sync+flush", nullptr};
+		static const char *const ph3[8] = {"loads+tables", "perm+sizes", "scan+offsets", "emit+pairs", "flush", nullptr, nullptr, nullptr};
 		report_stamps("K3 pack", d_st, slots3, ph3);
+		report_timeline("K3 pack", d_st, slots3);
 		(void)hipFree(d_st);
-	} else hipLaunchKernelGGL(pipe_pack_kernel<false>, dim3(n * NT), dim3(PW), 0, s, pa, (uint64_t *)nullptr);
+	} else hipLaunchKernelGGL(pipe_pack_kernel<false>, dim3(n * NT * 2), dim3(64), 0, s, pa, (uint64_t *)nullptr);
 	e = hipGetLastError();
 	if (timing) {
 		(void)hipEventRecord(ev[4], s);

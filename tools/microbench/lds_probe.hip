@@ -103,6 +103,36 @@ __global__ void __launch_bounds__(256) read_blocks_kernel(const uint16_t *in, in
 	if (acc == 0x12345678u) out[0] = acc;
 }
 
+// one wave per 64x32-pixel half tile of a 512x512 slice: lane = 8x4 pixels, four 16-byte row loads (eight 128-byte
+// lines per wave-instruction, 1 KB apart) -- the front end of encode_pipe.hip
+__global__ void __launch_bounds__(64) read_halftiles_kernel(const uint16_t *in, uint32_t *out, int rows_per_lane)
+{
+	const int ht = blockIdx.x & 127, sl = blockIdx.x >> 7;
+	const int tile = ht >> 1, half = ht & 1;
+	const int ty = tile >> 3, tx = tile & 7;
+	const int lane = threadIdx.x;
+	const uint16_t *p = in + (size_t)sl * 262144 + (size_t)(ty * 64 + half * 32 + (lane >> 3) * 4) * 512 + tx * 64 + (lane & 7) * 8;
+	uint32_t acc = 0;
+	for (int q = 0; q < rows_per_lane; q++) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(p + (size_t)q * 512);
+		acc += v.x ^ v.y ^ v.z ^ v.w;
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+// the same bytes, but a 256-lane workgroup reads 64 pixel rows x 64 pixels as whole 128-byte lines of ONE tile, four
+// lanes... variant B: workgroup = a band of 4 image rows x 512 pixels: every wave-instruction reads 1 KB contiguous
+__global__ void __launch_bounds__(256) read_bands_kernel(const uint16_t *in, uint32_t *out)
+{
+	// band = 16 rows of one slice (16 KB contiguous): lane reads 4 x 16 bytes at 4 KB stride
+	const size_t base = (size_t)blockIdx.x * 8192;  // pixels
+	uint32_t acc = 0;
+	for (int q = 0; q < 4; q++) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(in + base + (size_t)q * 2048 + threadIdx.x * 8);
+		acc += v.x ^ v.y ^ v.z ^ v.w;
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <class F>
 static float time_ms(F f, int reps)
 {
@@ -157,6 +187,10 @@ int main()
 	const float t_r = time_ms([&] { hipLaunchKernelGGL(read_raster_kernel, dim3(2048), dim3(256), 0, 0, (const uint4 *)d_img, bytes / 16, d_o32); }, 10);
 	const float t_b = time_ms([&] { hipLaunchKernelGGL(read_blocks_kernel, dim3(8192), dim3(256), 0, 0, d_img, 3 * 256 * 64, d_o32); }, 10);
 	const float t_b2 = time_ms([&] { hipLaunchKernelGGL(read_blocks_kernel, dim3(3 * 256 * 64), dim3(256), 0, 0, d_img, 3 * 256 * 64, d_o32); }, 10);
+	const float t_h = time_ms([&] { hipLaunchKernelGGL(read_halftiles_kernel, dim3(3 * 256 * 128), dim3(64), 0, 0, d_img, d_o32, 4); }, 10);
+	const float t_bd = time_ms([&] { hipLaunchKernelGGL(read_bands_kernel, dim3((unsigned)(bytes / 16384)), dim3(256), 0, 0, d_img, d_o32); }, 10);
+	printf("read 402 MB: half-tile waves (8 x 128-byte lines per instruction) %.3f ms = %.0f GB/s; 16-row bands (1 KB contiguous per instruction) %.3f ms = %.0f GB/s\n",
+	       t_h, bytes / t_h * 1e-6, t_bd, bytes / t_bd * 1e-6);
 	printf("read 402 MB: raster 16 B/lane %.3f ms = %.0f GB/s; 4x4 blocks 8 B/lane %.3f ms = %.0f GB/s (grid 8192), %.3f ms = %.0f GB/s (one tile per workgroup)\n",
 	       t_r, bytes / t_r * 1e-6, t_b, bytes / t_b * 1e-6, t_b2, bytes / t_b2 * 1e-6);
 	return 0;
