@@ -50,6 +50,7 @@ hipError_t launch_encode_tiles(const TileEncArgs &ta, int n, hipStream_t s);
 // staged pipeline (encode_pipe.hip): analyse -> resolve -> pack, tile-parallel, same applicability as the tile path
 // up to 1024x1024 (larger tiled shapes stay on encode_tiles_kernel)
 constexpr int PIPE_MAX_NB = 65536;          // blocks per slice (the resolve kernel keeps role[] in LDS)
+constexpr int PIPE_DEFAULT_MAX_NB = 16384;  // largest slice for which the pipeline is the default choice (see api.cpp)
 constexpr int PIPE_PAIR_REC = 80;           // bytes per meshed-pair record: jump byte + up to 64 token bytes, padded to 16
 constexpr uint32_t CCT_ST_INTERNAL = 0x80000000u;  // the kernels disagree about a size: a bug, never a data property
 struct PipeTiles {             // small per-shape tables carried IN the kernel arguments: one scalar load, no pointer to chase

@@ -339,13 +339,13 @@ def test_tile_path_equals_generic_path(hip, n_px):
     stride = payload_stride(w, h, 16)
     d_img = DeviceBuffer.from_numpy(imgs)
     res = []
-    for tile in (1, 2, 0):
+    for tile, ran in ((3, 1), (2, 2), (0, 0)):  # option value, implementation that must have run
         _ffi.check(L.cct_set_option(b"tile_path", tile))
         d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
         d_stats, d_roles = DeviceBuffer(16 * n), DeviceBuffer(n * nb)
         d_pay.zero()
         encode_payload_dev(d_img, n, w, h, codec_params(cfg, imgs.dtype), d_pay, d_sz, d_st, d_stats, d_roles)
-        assert _last_path(L) == tile
+        assert _last_path(L) == ran
         sizes = d_sz.download(np.uint32, n)
         res.append((sizes, d_st.download(np.uint32, n), d_stats.download(np.uint32, 4 * n),
                     d_roles.download(np.uint8, n * nb),
@@ -358,6 +358,19 @@ def test_tile_path_equals_generic_path(hip, n_px):
     assert not (res[0][1] & ~np.uint32(1)).any()
     for i in range(n):
         assert res[0][4][i] == oracle.encode(imgs[i], deflate=False)[13:]
+
+
+def test_default_path_by_shape(hip):
+    """The default choice among the tile paths: staged pipeline up to 512x512, one-workgroup-per-slice kernel at 1024x1024."""
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    cfg = hip.default_config()
+    hip.encode_batch(gi.ct_phantom(3, 512)[None], cfg)
+    assert _last_path(L) == 1
+    hip.encode_batch(gi.ct_phantom(3, 1024)[None], cfg)
+    assert _last_path(L) == 2
+    hip.encode_batch(gi.ct_phantom(3, 64)[None], cfg)   # one tile only: not a tiled shape -> generic kernel
+    assert _last_path(L) == 0
 
 
 def test_pipeline_signed_and_flag_variants(hip):

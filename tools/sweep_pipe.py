@@ -36,9 +36,8 @@ def main():
     reps = 2 if os.environ.get("CCT_PIPE_STAMPS") else 12
     tpw3s = [int(x) for x in os.environ.get("TPW3", "0").split(",")]
     L.cct_set_option(b"debug_skip", int(os.environ.get("DBG", "0")))
-    ways_list = [int(x) for x in os.environ.get("WAYS", "0").split(",")]
+    ways_list = [0]
     for tpw in [t for t in tpws for _ in ways_list]:
-        tpw3 = ways_list[0]; ways_list.append(ways_list.pop(0))
         L.cct_set_option(b"pipe_tpw", tpw)
         rows = []
         for it in range(reps + 2):
@@ -48,7 +47,7 @@ def main():
                 L.cct_get_option(f"pipe_us_k{i + 1}".encode(), C.byref(v[i]))
             rows.append([x.value / 10.0 for x in v])
         med = np.median(np.array(rows[2:]), axis=0)
-        print(f"tpw {tpw} ways {tpw3}: analyse {med[0]:7.1f}  masks {med[1]:7.1f}  resolve {med[2]:7.1f}  pack {med[3]:7.1f}  sum {med.sum():7.1f} us", flush=True)
+        print(f"tpw {tpw}: analyse {med[0]:7.1f}  masks {med[1]:7.1f}  resolve {med[2]:7.1f}  pack {med[3]:7.1f}  sum {med.sum():7.1f} us", flush=True)
     L.cct_set_option(b"debug_skip", 0)
     L.cct_set_option(b"pipe_timing", 0)
     L.cct_set_option(b"pipe_tpw", 0)
