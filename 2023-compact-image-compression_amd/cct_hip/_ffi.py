@@ -72,6 +72,9 @@ _SIGS = {
                                          C.c_int, C.c_void_p, C.c_void_p]),
     "cct_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int,
                                    C.c_size_t, C.c_void_p]),
+    "cct_packbits_bound": (C.c_size_t, [C.c_size_t]),
+    "cct_packbits_encode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cct_packbits_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "cct_last_timings": (C.c_int, [C.POINTER(C.c_float)]),
     "cct_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "cct_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),

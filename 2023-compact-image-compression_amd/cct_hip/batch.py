@@ -167,6 +167,20 @@ def decode_payload_dev(d_payload, stride, d_sizes, n, width, height, block_size,
                                                   int(bool(fractal)), d_images.ptr, d_status.ptr))
 
 
+def partition_roles(image, config=None):
+    """Block roles of one slice (the partition of cluster.py:49-199 as the device computes it): uint8[NB], 0 = emitted
+    alone, 1..63 = leader of a meshed pair (BLOCK_JUMPS[b] - b), 0xFF = partner."""
+    config = config or default_config()
+    image = np.ascontiguousarray(image)
+    w, h = image.shape
+    bs = int(config["block_size"])
+    nb = w * h // bs
+    d_img = DeviceBuffer.from_numpy(image)
+    d_pay, d_sz, d_st, d_roles = DeviceBuffer(payload_stride(w, h, bs)), DeviceBuffer(4), DeviceBuffer(4), DeviceBuffer(max(nb, 1))
+    encode_payload_dev(d_img, 1, w, h, codec_params(config, image.dtype), d_pay, d_sz, d_st, None, d_roles)
+    return d_roles.download(np.uint8, nb)
+
+
 def encode_batch(images, config=None, return_info=False):
     """images: (n, W, H) array of a 2-byte dtype (or a DeviceBuffer + shape via encode_batch_dev).
     Returns a list of n `bytes`, each exactly what Encoder(config, images[i]).encode() returns."""

@@ -53,6 +53,60 @@ def _magic_int(config):
     return int.from_bytes(bytes(map(ord, reversed(config["magic"]))), sys.byteorder)
 
 
+class ByteWriter:
+    """Header and payload kept apart, as core.py:95-131 does; filled from the device results."""
+
+    def __init__(self):
+        self.header = bytearray()
+        self.data = bytearray()
+
+    def set_data(self, data):
+        self.data = data
+
+    def output_header(self):
+        return bytes(self.header)
+
+    def output_data(self):
+        return bytes(self.data)
+
+    def output(self):
+        return bytes(self.header) + bytes(self.data)
+
+
+def final_pixel_order(order, roles, block_size):
+    """PIXEL_ORDER and BLOCK_JUMPS of BlockPartitioner.block_partition (cluster.py:49-199) from the block roles the
+    device computed: role 0 = block emitted alone, 1..63 = leader meshed with block + role (its pixels interleaved,
+    cluster.py:173-174), 0xFF = partner (emitted with its leader)."""
+    blocks = np.asarray(order, dtype=np.int32).reshape(-1, block_size)
+    out, jumps = [], {}
+    for b, r in enumerate(np.asarray(roles, dtype=np.uint8).tolist()):
+        if r == 0:
+            out.append(blocks[b])
+        elif r != 0xFF:
+            jumps[b] = b + r
+            pair = np.empty(2 * block_size, dtype=np.int32)
+            pair[0::2] = blocks[b]
+            pair[1::2] = blocks[b + r]
+            out.append(pair)
+    return (np.concatenate(out) if out else np.zeros(0, np.int32)), jumps
+
+
+class _Partition:
+    """What callers read from Encoder.partition (core.py:258): block_partition() -> (PIXEL_ORDER, BLOCK_JUMPS).  The
+    partition itself is computed on the device (cct_encode_payload_dev's role table)."""
+
+    def __init__(self, image, config, order):
+        self._image, self._config, self._order = image, config, order
+        self.block_size = int(config["block_size"])
+        self._result = None
+
+    def block_partition(self):
+        if self._result is None:
+            roles = batch.partition_roles(self._image, self._config)
+            self._result = final_pixel_order(self._order, roles, self.block_size)
+        return self._result
+
+
 class Encoder:
 
     def __init__(self, config, image, out_path=None):
@@ -64,10 +118,19 @@ class Encoder:
         self.out_path = out_path
         self.stats = [["Section", "Size (KB)", "Ratio (x)"]]
         self.info = defaultdict(int)
+        self.writer = ByteWriter()  # core.py:182
 
     @property
     def MAGIC(self):
         return _magic_int(self.config)
+
+    def _traversal(self):
+        """core.py:234-239: the traversal object (fractal on) and the pixel order."""
+        if self.config["encoder"]["transforms"]["fractal"]:
+            from .curve import GeneralizedHilbertCurve
+            self.curve = GeneralizedHilbertCurve(self.width, self.height, get_index=True)
+            return np.asarray(self.curve.generate_all(), dtype=np.int32)
+        return np.arange(self.size, dtype=np.int32)
 
     def encode(self):
         cfg = self.config
@@ -86,6 +149,12 @@ class Encoder:
 
         files, info = batch.encode_batch(np.ascontiguousarray(self.image)[None, :, :], cfg, return_info=True)
         output, st = files[0], info[0]
+        self.writer.header = bytearray(output[:13])   # core.py:193-210
+        self.writer.set_data(output[13:])             # core.py:337-345: the payload, DEFLATEd when configured
+        if enc["transforms"]["segmentation"]:         # core.py:258-268 (evaluated lazily: one more device call when asked for)
+            self.partition = _Partition(np.ascontiguousarray(self.image), cfg, self._traversal())
+        elif enc["transforms"]["fractal"]:
+            self._traversal()
         self.info["delta"] = st["n_short"]
         self.info["full"] = st["n_full"]
         self.block_jumps_count = st["n_jump"]
@@ -120,7 +189,30 @@ class Decoder:
         self.config = config
         self.file_bytes = file_bytes
         self.out_path = out_path
-        self.fulls = []  # the reference collects full-token positions for debugging only
+        self._fulls = None
+        self._pixels = None
+
+    @property
+    def fulls(self):
+        """core.py:508: raster indices of the pixels that arrived as full (two-byte) tokens, in stream order.  The
+        reference collects them while parsing; here they are recomputed on demand from the decoded slice (the order
+        the pixels were written in is the encoder's partition of that same slice)."""
+        if self._fulls is None:
+            if self._pixels is None:
+                return []
+            cfg = self.config
+            order = np.arange(self.size, dtype=np.int32)
+            if self.fractal_transform:
+                from .curve import GeneralizedHilbertCurve
+                order = np.asarray(GeneralizedHilbertCurve(self.width, self.height, get_index=True).generate_all(), np.int32)
+            # jump handling is unconditional in the decoder (SURVEY App. A Q9): a file written without segmentation has no jumps
+            if self.segmentation_transform:
+                roles = batch.partition_roles(self._pixels, cfg)
+                order, _ = final_pixel_order(order, roles, int(cfg["block_size"]))
+            vals = self._pixels.reshape(-1)[order].astype(np.int64)
+            delta = np.diff(np.concatenate([[0], vals]))
+            self._fulls = order[(delta < -63) | (delta > 64)].tolist()
+        return self._fulls
 
     @property
     def MAGIC(self):
@@ -146,6 +238,7 @@ class Decoder:
         self.size = self.width * self.height
         self.total_size = self.size * self.channels * self.bytes_per_channel
         pixels = batch.decode_batch([bytes(self.file_bytes)], self.config)[0]  # (width, height) uint16
+        self._pixels = pixels
 
         if self.out_path is not None:  # core.py:522-540: 16-bit PNG preview, value << 4
             preview = (pixels.astype(np.uint32) << 4).astype(np.uint16)

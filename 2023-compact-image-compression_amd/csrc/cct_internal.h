@@ -163,4 +163,10 @@ struct InflateArgs {
 };
 hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st);
 
+// ---- PackBits utility (packbits_kernels.hip) -------------------------------------------------
+hipError_t launch_packbits_encode(const uint8_t *d_in, const uint64_t *d_offsets, int n, int delta, uint32_t *d_ws, uint8_t *d_out,
+                                  size_t out_stride, uint32_t *d_out_sizes, hipStream_t st);
+hipError_t launch_packbits_decode(const uint8_t *d_in, const uint64_t *d_offsets, int n, int delta, uint8_t *d_out, size_t out_stride,
+                                  uint32_t *d_out_sizes, uint32_t *d_status, hipStream_t st);
+
 }  // namespace cct

@@ -183,6 +183,17 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
                      const char magic[4], uint16_t *images, int images_on_device,
                      size_t images_cap_px, uint32_t *h_status /* CCT_E_* code per file */);
 
+/* ---- PackBits utility -------------------------------------------------------------- */
+/* Replaces PackBits(apply_delta_transform).encode / .decode of src/codec/packbits.py:74-163 (dead code in the reference:
+ * nothing imports it, the .cct path never runs it) for n byte strings h_in[h_offsets[i] .. h_offsets[i+1]).
+ * Output i lands at h_out + i*out_stride.  Encode needs out_stride >= cct_packbits_bound(longest input); decode reports
+ * CCT_E_CAP per string when out_stride is too small and CCT_E_STREAM for a run header without its byte. */
+size_t cct_packbits_bound(size_t n_bytes);
+int cct_packbits_encode_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, int delta_transform,
+                              uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes);
+int cct_packbits_decode_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, int delta_transform,
+                              uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status);
+
 /* ---- tuning / introspection (bench.py) --------------------------------------------- */
 /* Stage times of the CALLING THREAD's most recent cct_encode_batch / cct_decode_batch, milliseconds (kept per
  * thread: an encode and a decode driven from two threads do not overwrite each other; takes no lock):

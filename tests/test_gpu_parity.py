@@ -497,3 +497,64 @@ def test_config4_full_batch_512(hip):
         assert files[i] == oracle.encode(imgs[i])
     back = hip.decode_batch(files, cfg)
     assert np.array_equal(back, imgs)
+
+
+def test_tools_demo_and_evaluate(hip, tmp_path, capsys):
+    """the pydicom-free counterparts of scripts/demo.py and scripts/evaluate.py on the two real slices:
+    demo's checks (zero error, equal SHA-1, demo.py:85-103) and get_filename naming (demo.py:16-25); evaluate's CSV with
+    the CCT sizes of results/encoder-comparisons.csv:628,3618 (207 575 and 205 179 bytes) and its ZIP column
+    (270 969 and 273 262)."""
+    import importlib.util
+    tools = os.path.join(os.path.dirname(gi.HERE), "tools")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    demo, evaluate = load("demo"), load("evaluate")
+    src = tmp_path / "corpus"
+    src.mkdir()
+    np.save(src / "1-016.npy", gi.load_slice("slice0671"))
+    np.save(src / "1-55.npy", gi.load_slice("slice3706"))
+    work = tmp_path / "working"
+    assert demo.main([str(src / "1-016.npy"), "--workdir", str(work)]) == 0
+    out = capsys.readouterr().out
+    assert "Total Error: 0" in out and out.count("bc26ff59b9950f2b9857856aec4561c351cf146f") == 2
+    with open(os.path.join(gi.GOLDEN, "slice0671.cct"), "rb") as f:
+        assert (work / "testing.cct").read_bytes() == f.read()
+    cfg = hip.default_config()
+    assert demo.get_filename("data/working/testing.cct", False, cfg) == "data/working/decoded-testing.png"
+    assert demo.get_filename("x/y/1-016.dcm", True, cfg) == "x/y/encoded-1-016.cct"
+    assert (work / "decoded-testing.png").exists()
+    csv_path = tmp_path / "evaluation.csv"
+    assert evaluate.main([str(src), "--results", str(csv_path)]) == 0
+    lines = csv_path.read_text().splitlines()
+    assert lines[0] == "File,Raw,ZIP,PNG,RLE,JP2,CCT"
+    rows = {ln.split(",")[0]: ln.split(",") for ln in lines[1:]}
+    a, b = rows["(0000)-1-016.npy"], rows["(0001)-1-55.npy"]
+    assert (a[1], a[2], a[6]) == ("524288", "270969", "207575")
+    assert (b[1], b[2], b[6]) == ("524288", "273262", "205179")
+
+
+def test_encoder_decoder_reference_attributes(hip):
+    """Attributes callers of the reference read after encode()/decode(): Encoder.writer (core.py:182), .curve
+    (core.py:235), .partition.block_partition() (core.py:258-268; oracle/gen_golden.py relies on it) and Decoder.fulls
+    (core.py:508)."""
+    from codec.core import Decoder, Encoder
+    cfg = hip.default_config()
+    cfg["verbose"] = False
+    case = CASES["slice0671"]
+    img = gi.load_slice("slice0671")
+    enc = Encoder(cfg, img)
+    out = enc.encode()
+    assert enc.writer.output() == out and len(enc.writer.output_header()) == 13 and enc.writer.output_data() == out[13:]
+    assert enc.curve.generate_all()[:4] == [0, 512, 513, 1]
+    order, jumps = enc.partition.block_partition()
+    assert len(jumps) == case["tokens"]["jump"]
+    assert hashlib.sha1(np.array(sorted(jumps.items()), dtype=np.int32).tobytes()).hexdigest() == case["jumps_sha1"]
+    assert sorted(order.tolist()) == list(range(512 * 512))
+    dec = Decoder(cfg, out)
+    dec.decode()
+    assert len(dec.fulls) == case["tokens"]["full"]
