@@ -72,6 +72,11 @@ _SIGS = {
                                          C.c_int, C.c_void_p, C.c_void_p]),
     "cct_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_int,
                                    C.c_size_t, C.c_void_p]),
+    "cct_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cct_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cct_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cct_allgather_u32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cct_comm_destroy": (C.c_int, []),
     "cct_packbits_bound": (C.c_size_t, [C.c_size_t]),
     "cct_packbits_encode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cct_packbits_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -96,14 +96,15 @@ class _Partition:
     partition itself is computed on the device (cct_encode_payload_dev's role table)."""
 
     def __init__(self, image, config, order):
-        self._image, self._config, self._order = image, config, order
+        self._image, self._config, self._order = image, config, order  # order: the traversal, or a callable that makes it
         self.block_size = int(config["block_size"])
         self._result = None
 
     def block_partition(self):
         if self._result is None:
             roles = batch.partition_roles(self._image, self._config)
-            self._result = final_pixel_order(self._order, roles, self.block_size)
+            order = self._order() if callable(self._order) else self._order
+            self._result = final_pixel_order(order, roles, self.block_size)
         return self._result
 
 
@@ -119,16 +120,25 @@ class Encoder:
         self.stats = [["Section", "Size (KB)", "Ratio (x)"]]
         self.info = defaultdict(int)
         self.writer = ByteWriter()  # core.py:182
+        self._curve = None
 
     @property
     def MAGIC(self):
         return _magic_int(self.config)
 
-    def _traversal(self):
-        """core.py:234-239: the traversal object (fractal on) and the pixel order."""
-        if self.config["encoder"]["transforms"]["fractal"]:
+    @property
+    def curve(self):
+        """core.py:234-235: the traversal object (only with the fractal transform on); built when somebody asks."""
+        if not self.config["encoder"]["transforms"]["fractal"]:
+            raise AttributeError("curve")
+        if self._curve is None:
             from .curve import GeneralizedHilbertCurve
-            self.curve = GeneralizedHilbertCurve(self.width, self.height, get_index=True)
+            self._curve = GeneralizedHilbertCurve(self.width, self.height, get_index=True)
+        return self._curve
+
+    def _traversal(self):
+        """core.py:234-239: the pixel order."""
+        if self.config["encoder"]["transforms"]["fractal"]:
             return np.asarray(self.curve.generate_all(), dtype=np.int32)
         return np.arange(self.size, dtype=np.int32)
 
@@ -152,9 +162,7 @@ class Encoder:
         self.writer.header = bytearray(output[:13])   # core.py:193-210
         self.writer.set_data(output[13:])             # core.py:337-345: the payload, DEFLATEd when configured
         if enc["transforms"]["segmentation"]:         # core.py:258-268 (evaluated lazily: one more device call when asked for)
-            self.partition = _Partition(np.ascontiguousarray(self.image), cfg, self._traversal())
-        elif enc["transforms"]["fractal"]:
-            self._traversal()
+            self.partition = _Partition(np.ascontiguousarray(self.image), cfg, self._traversal)
         self.info["delta"] = st["n_short"]
         self.info["full"] = st["n_full"]
         self.block_jumps_count = st["n_jump"]

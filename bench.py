@@ -12,7 +12,8 @@ Workloads (BASELINE.json `configs`):
   --config 4  the same pipeline on 512 slices of 1024x1024 per step (1.07 GB of pixels: HBM for certain).
   --config 5  decode only: the archives of config 2 are encoded once outside the timed region; a step decodes one.
 Slices shard across GPUs with no data-path collective (weak scaling: the same number of slices per GPU per step); the
-only exchange is the all-gather of the per-slice compressed sizes over RCCL.
+only exchange is the all-gather of the per-slice compressed sizes over RCCL, reached through the library's C ABI
+(cct_comm_init / cct_allgather_u32; the communicator id travels from rank 0 through a file): no PyTorch in this script.
 
 One JSON line on stdout (rank 0): metric/value as the driver contract says, plus
   roofline      the transform+pack stage (the four kernels of encode_pipe.hip; decode-only: INFLATE + decode kernel):
@@ -175,19 +176,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batches[0])
 
-    dist = None
-    if args.gpus > 1 or world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()
-
     import cct_hip
-    from cct_hip import _ffi
-    from cct_hip.parallel import gather_sizes
+    from cct_hip import _ffi, parallel
     L = _ffi.lib()
     _ffi.check(L.cct_init(local_rank))
+    multi = world > 1
+    if multi:  # one process per GPU; RCCL through the library's C ABI (no PyTorch in the data path or around it)
+        parallel.comm_init(rank, world)
+
+    def gather_sizes(local_sizes):
+        return parallel.gather_sizes_rccl(local_sizes) if multi else np.asarray(local_sizes, dtype=np.uint32).copy()
+
     info = cct_hip.device_info()
     # host team: the library sizes it from the CPUs this process may use (cgroup quota aware); ranks of one node share them
     zt = C.c_int(0)
@@ -274,27 +273,25 @@ def main():
             if prev is not None:                # at most two encodes in flight
                 prev[0].result()
                 t1 = time.perf_counter()
-                state["sizes"] = gather_sizes(h_sizes[prev[1]], dist, local_rank)  # RCCL all-gather of compressed sizes
+                state["sizes"] = gather_sizes(h_sizes[prev[1]])  # RCCL all-gather of compressed sizes
                 if record:
                     acc["gather"] += (time.perf_counter() - t1) * 1e3
             prev = None if not overlap else (e, k)
         if prev is not None:
             prev[0].result()
-            state["sizes"] = gather_sizes(h_sizes[prev[1]], dist, local_rank)
+            state["sizes"] = gather_sizes(h_sizes[prev[1]])
         while in_flight:
             in_flight.pop(0).result()
 
     def barrier():
         _ffi.check(L.cct_sync())
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        if multi:
+            parallel.barrier()
 
     if decode_only:  # the archives are produced once, outside the timed region
         for k in range(NSET):
             enc_step(k, k, True)
-        state["sizes"] = gather_sizes(h_sizes[0], dist, local_rank)
+        state["sizes"] = gather_sizes(h_sizes[0])
         acc["n_enc"] = max(1, acc["n_enc"])
     run_steps(0, args.warmup, False)
     barrier()
@@ -302,11 +299,8 @@ def main():
     run_steps(args.warmup, args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if multi:
+        elapsed = parallel.allreduce_max_float(elapsed)
 
     # ---- verification outside the timed region: exact round trip + oracle bytes on a sample
     last_i = args.warmup + args.steps - 1
@@ -402,9 +396,9 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if multi:
+        parallel.barrier()
+        _ffi.check(L.cct_comm_destroy())
     if not verified:
         sys.exit(3)
 

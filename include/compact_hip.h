@@ -183,6 +183,22 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
                      const char magic[4], uint16_t *images, int images_on_device,
                      size_t images_cap_px, uint32_t *h_status /* CCT_E_* code per file */);
 
+/* ---- multi-GPU: the path's only exchange step ----------------------------------------- */
+/* Slices shard over GPUs with no data-path collective (scripts/evaluate.py:107-119 treats them as independent units too);
+ * what ranks exchange is the per-slice compressed size, so that every rank knows every file's offset in the archive.
+ * One process per GPU.  RCCL (librccl.so, loaded on first use) carries the all-gather over xGMI.  Bootstrap: rank 0 calls
+ * cct_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the launcher has (bench.py: a file
+ * next to the rendezvous port); then every rank calls cct_comm_init.  No PyTorch anywhere. */
+#define CCT_COMM_ID_BYTES 128
+int cct_comm_unique_id(void *id128);                             /* ncclGetUniqueId */
+int cct_comm_init(const void *id128, int rank, int world);        /* ncclCommInitRank on the library's device */
+int cct_comm_info(int *rank, int *world);                         /* -1, 0 when no communicator exists */
+/* every rank passes its n_local values and the same max_local >= every rank's n_local; h_all receives world * max_local
+ * values, rank r's at h_all[r * max_local ..] (the caller trims by the counts it gathers the same way).  Without a
+ * communicator: a plain copy (single-process use). */
+int cct_allgather_u32(const uint32_t *h_local, int n_local, int max_local, uint32_t *h_all);
+int cct_comm_destroy(void);
+
 /* ---- PackBits utility -------------------------------------------------------------- */
 /* Replaces PackBits(apply_delta_transform).encode / .decode of src/codec/packbits.py:74-163 (dead code in the reference:
  * nothing imports it, the .cct path never runs it) for n byte strings h_in[h_offsets[i] .. h_offsets[i+1]).

@@ -558,3 +558,22 @@ def test_encoder_decoder_reference_attributes(hip):
     dec = Decoder(cfg, out)
     dec.decode()
     assert len(dec.fulls) == case["tokens"]["full"]
+
+
+def test_rccl_communicator_of_one(hip):
+    """The C-ABI exchange step on real RCCL: a communicator of one rank (all this box has), id through the file rendezvous,
+    all-gather of sizes, destroy.  The N > 1 case differs only in the number of ranks."""
+    import ctypes as C
+    from cct_hip import _ffi, parallel
+    L = _ffi.lib()
+    parallel.comm_init(0, 1)
+    try:
+        rk, wd = C.c_int(-5), C.c_int(-5)
+        _ffi.check(L.cct_comm_info(C.byref(rk), C.byref(wd)))
+        assert (rk.value, wd.value) == (0, 1)
+        sizes = np.array([207575, 205179, 1, 2, 3], dtype=np.uint32)
+        assert np.array_equal(parallel.gather_sizes_rccl(sizes), sizes)
+        assert np.array_equal(parallel.file_offsets(parallel.gather_sizes_rccl(sizes))[-1:], [sizes.sum()])
+        parallel.barrier()
+    finally:
+        _ffi.check(L.cct_comm_destroy())

@@ -65,3 +65,35 @@ def test_shard_range_covers_everything():
             assert got == list(range(n))
     assert shard_range(3954, 0, 8) == (0, 495) and shard_range(3954, 2, 8) == (990, 1484) and shard_range(3954, 7, 8) == (3460, 3954)
     assert sorted({hi - lo for lo, hi in (shard_range(3954, r, 8) for r in range(8))}) == [494, 495]
+
+
+def _id_worker(rank, d, q):
+    import os
+    os.environ.pop("MASTER_PORT", None)
+    from cct_hip.parallel import exchange_unique_id
+    blob, _ = exchange_unique_id(rank, 2, lambda: bytes(range(128)), directory=d, key="unit", timeout_s=20)
+    q.put((rank, blob))
+
+
+def test_unique_id_file_rendezvous(tmp_path):
+    """bench.py's N > 1 bootstrap without PyTorch: rank 0 leaves the 128-byte communicator id in a file, the others wait."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_id_worker, args=(r, str(tmp_path), q)) for r in (1, 0)]  # the reader starts first
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert got[0] == got[1] == bytes(range(128))
+
+
+def test_allgather_without_communicator_is_a_copy():
+    """cct_allgather_u32 / gather_sizes_rccl in a single process (no communicator): identity, no device needed."""
+    import numpy as np
+    from cct_hip import parallel
+    v = np.arange(7, dtype=np.uint32) * 1000
+    assert np.array_equal(parallel.allgather_u32(v, 9)[0], np.concatenate([v, [0, 0]]))
+    assert np.array_equal(parallel.gather_sizes_rccl(v), v)
+    assert abs(parallel.allreduce_max_float(1.25) - 1.25) < 1e-6
