@@ -91,9 +91,6 @@ struct Context {
 	pid_t pid = 0;
 	int device = -1;
 	hipStream_t stream = nullptr;
-	hipStream_t stream_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t ev_z[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t ev_zfork = nullptr;
 	// packed archives leave the device on their own stream from one of two buffers, after the device lock has
 	// been released: the next encode call may start its kernels while this one's files are still on the wire
 	// the ~25 launches of one DEFLATE pass, captured once per argument set and replayed as a graph: fewer host
@@ -106,7 +103,6 @@ struct Context {
 	hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
 	DevBuf z_packed2[2];
 	unsigned pack_slot = 0;
-	int deflate_ways = 1;  // option "deflate_ways" (1..8): 2 is ~8 % faster alone but unstable next to a concurrent decode stream
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths, 3 staged pipeline (encode_pipe.hip) wherever it
@@ -159,11 +155,23 @@ int default_device()
 	return lr ? atoi(lr) : 0;
 }
 
+// Asynchronous copies that target locals (std::vector on the stack frame) or caller memory must have landed before an
+// error return unwinds the frame: declare one of these AFTER those locals; it drains the stream unless disarmed.
+struct DrainOnExit {
+	hipStream_t s; bool armed = true;
+	explicit DrainOnExit(hipStream_t st) : s(st) {}
+	~DrainOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+	void disarm() { armed = false; }
+};
+
 int ensure_ctx(int device = -1)
 {
 	if (g_ctx.ready && g_ctx.pid != getpid()) {
-		// forked child: the parent's HIP state is unusable here; start clean (nothing is freed)
-		g_ctx = Context();
+		// A child forked AFTER the parent initialised the device inherits a HIP runtime it cannot use (ROCm does not
+		// support that state, and re-creating the context on top of it is not safe either).  Callers that fan work out over
+		// processes (scripts/evaluate.py:107) must fork before the first device call: each child then initialises its own.
+		return fail(CCT_E_DEVICE, "this process was forked after the library had initialised the GPU in its parent (pid %d): "
+		                          "fork workers before the first cct_* device call", (int)g_ctx.pid);
 	}
 	if (g_ctx.ready) {
 		if (device >= 0 && device != g_ctx.device)
@@ -614,19 +622,10 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
 	if ((rc = g_ctx.z_out.ensure((size_t)n * out_stride))) return rc;
 	if ((rc = g_ctx.z_outsizes.ensure((size_t)n * 4))) return rc;
-	// The pipeline's kernels are latency-bound (one-lane tree builds, serial block walks, long-chain
-	// tails), so the batch is cut into up to DEFLATE_WAYS slice ranges that run concurrently on their
-	// own streams and share the chip.
-	const int ways = std::max(1, std::min(g_ctx.deflate_ways, n));
-	const int per_way = (n + ways - 1) / ways;
-	const size_t tmp = (deflate_sort_temp_bytes((size_t)per_way * in_stride, per_way) + 511) & ~(size_t)255;
-	if ((rc = g_ctx.z_sorttmp.ensure(tmp * ways + 256))) return rc;
-	for (int w = 0; w < ways; w++)
-		if (!g_ctx.stream_z[w]) {
-			HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_z[w], hipStreamNonBlocking));
-			HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_z[w], hipEventDisableTiming));
-		}
-	if (!g_ctx.ev_zfork) HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_zfork, hipEventDisableTiming));
+	// (cutting the batch into slice ranges that run concurrently on streams of their own was tried and removed: the
+	// cross-stream dependencies cost more than the overlap returned, here as in the transform+pack stage)
+	const size_t tmp = (deflate_sort_temp_bytes((size_t)n * in_stride, n) + 511) & ~(size_t)255;
+	if ((rc = g_ctx.z_sorttmp.ensure(tmp + 256))) return rc;
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
 	a.keys_in = (uint16_t *)g_ctx.z_keys_in.p; a.keys_out = (uint16_t *)g_ctx.z_keys_out.p;
@@ -644,7 +643,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 	a.max_blocks = max_blocks;
 	a.out = (uint8_t *)g_ctx.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)g_ctx.z_outsizes.p;
 	memcpy(a.header13, header13, 13);
-	if (ways == 1 && g_ctx.use_graph) {
+	if (g_ctx.use_graph) {
 		// whole batch on the main stream, as a graph keyed by everything the launches depend on
 		std::vector<uint8_t> key(sizeof(DeflateArgs) + sizeof(int));
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
@@ -663,27 +662,7 @@ int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_s
 		HIP_TRY(hipGraphLaunch(g_ctx.z_graph_exec, g_ctx.stream));
 		return CCT_OK;
 	}
-	HIP_TRY(hipEventRecord(g_ctx.ev_zfork, g_ctx.stream));  // inputs are produced on the main stream
-	for (int w = 0; w < ways; w++) {
-		const int s0 = w * per_way, ns = std::min(per_way, n - s0);
-		if (ns <= 0) break;
-		DeflateArgs b = a;
-		const size_t eo = (size_t)s0 * in_stride, bo = (size_t)s0 * (in_stride / 64), mo = (size_t)s0 * max_blocks;
-		b.in += eo; b.in_sizes += s0;
-		b.keys_in += eo; b.keys_out += eo; b.vals_in += eo; b.vals_out += eo;
-		b.seg_begin += s0; b.seg_end += s0; b.total_syms += s0; b.postloop_lit += s0; b.n_blocks += s0; b.adler += s0;
-		b.heavy_count += s0; b.deep_count += s0; b.run_end_count += s0; b.sort_hist += (size_t)s0 * 128;
-		b.mr = (uint8_t *)b.mr + eo * 8; b.heavy_list += eo; b.sym += eo; b.run_ends += eo; b.run_len += eo;
-		b.rec32 += eo; b.exit_pos += eo; b.exit_cnt += eo;
-		b.blk_entry += bo; b.blk_symbase += bo;
-		b.blk_end += mo; b.block_meta += mo; b.block_tables += mo;
-		b.out += (size_t)s0 * out_stride; b.out_sizes += s0;
-		hipStream_t st = g_ctx.stream_z[w];
-		HIP_TRY(hipStreamWaitEvent(st, g_ctx.ev_zfork, 0));
-		HIP_TRY(launch_deflate(b, ns, (uint8_t *)g_ctx.z_sorttmp.p + (size_t)w * tmp, tmp, st));
-		HIP_TRY(hipEventRecord(g_ctx.ev_z[w], st));
-		HIP_TRY(hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_z[w], 0));  // join
-	}
+	HIP_TRY(launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream));
 	return CCT_OK;
 }
 
@@ -723,6 +702,40 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	return CCT_OK;
 }
 
+// ---- RCCL through dlopen: the library carries no link-time dependency on librccl (573 MB) ------------------
+struct Rccl {
+	void *h = nullptr;
+	int (*GetUniqueId)(void *) = nullptr;
+	int (*CommInitRank)(void **, int, cct_unique_id_t, int) = nullptr;
+	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+	int (*CommDestroy)(void *) = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+	void *comm = nullptr;
+	int rank = -1, world = 0;
+	DevBuf d_send, d_recv;
+} g_rccl;
+
+int rccl_load()
+{
+	if (g_rccl.h) return CCT_OK;
+	void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+	if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!h) return fail(CCT_E_DEVICE, "cannot load librccl: %s", dlerror());
+	g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+	g_rccl.CommInitRank = (int (*)(void **, int, cct_unique_id_t, int))dlsym(h, "ncclCommInitRank");
+	g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+	g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+	g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+	if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) { dlclose(h); return fail(CCT_E_DEVICE, "librccl lacks an expected symbol"); }
+	g_rccl.h = h;
+	return CCT_OK;
+}
+int rccl_fail(const char *what, int rc)
+{
+	return fail(CCT_E_DEVICE, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+
 }  // namespace
 }  // namespace cct
 
@@ -745,21 +758,32 @@ int cct_shutdown(void)
 	if (!g_ctx.ready || g_ctx.pid != getpid()) { g_ctx = Context(); return CCT_OK; }
 	(void)hipSetDevice(g_ctx.device);
 	(void)hipStreamSynchronize(g_ctx.stream);
-	for (auto &kv : g_ctx.luts) { (void)hipFree(kv.second.d_lut); (void)hipFree(kv.second.d_org); (void)hipFree(kv.second.d_orient); (void)hipFree(kv.second.d_pat); }
+	(void)hipStreamSynchronize(g_ctx.stream_dec);
+	if (g_ctx.stream_copy) (void)hipStreamSynchronize(g_ctx.stream_copy);
+	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; g_rccl.rank = -1; g_rccl.world = 0; }
+	g_rccl.d_send.release(); g_rccl.d_recv.release();
+	for (auto &kv : g_ctx.luts) {
+		ShapeTables &t = kv.second;
+		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
+		for (void *p : ptrs) if (p) (void)hipFree(p);
+	}
+	if (g_ctx.z_graph_exec) (void)hipGraphExecDestroy(g_ctx.z_graph_exec);
+	if (g_ctx.z_graph) (void)hipGraphDestroy(g_ctx.z_graph);
 	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
 	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
 	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.d_pcache, &g_ctx.h_stage,
 	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
 	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
-	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs, &g_ctx.z_packed2[0], &g_ctx.z_packed2[1]};
+	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs, &g_ctx.z_packed2[0], &g_ctx.z_packed2[1],
+	                  &g_ctx.e_toff, &g_ctx.e_pairrec, &g_ctx.e_spill, &g_ctx.e_tflag, &g_ctx.d_arch, &g_ctx.d_archoffs, &g_ctx.d_zstatus};
 	for (DevBuf *b : bufs) b->release();
-	(void)hipEventDestroy(g_ctx.ev_k0);
-	(void)hipEventDestroy(g_ctx.ev_k1);
-	(void)hipEventDestroy(g_ctx.ev_d0);
-	(void)hipEventDestroy(g_ctx.ev_d1);
+	hipEvent_t evs[] = {g_ctx.ev_k0, g_ctx.ev_k1, g_ctx.ev_d0, g_ctx.ev_d1, g_ctx.ev_z0, g_ctx.ev_z1, g_ctx.ev_k_dec0, g_ctx.ev_k_dec1,
+	                    g_ctx.ev_pack[0], g_ctx.ev_pack[1], g_ctx.ev_copied[0], g_ctx.ev_copied[1]};
+	for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	g_ctx.dh_stage.release();
 	(void)hipStreamDestroy(g_ctx.stream);
 	(void)hipStreamDestroy(g_ctx.stream_dec);
+	if (g_ctx.stream_copy) (void)hipStreamDestroy(g_ctx.stream_copy);
 	g_ctx = Context();
 	return CCT_OK;
 }
@@ -845,6 +869,7 @@ int cct_dev_memset(void *d_dst, int value, size_t bytes)
 	int rc = ensure_ctx();
 	if (rc) return rc;
 	HIP_TRY(hipMemsetAsync(d_dst, value, bytes, g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(g_ctx.stream));  // complete on return: decode calls run on their own stream
 	return CCT_OK;
 }
 int cct_sync(void)
@@ -968,6 +993,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	if (h_stats)
 		HIP_TRY(hipMemcpyAsync(h_stats, g_ctx.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, g_ctx.stream));
 	std::vector<uint32_t> psz(n);
+	DrainOnExit drain(g_ctx.stream);  // until the first synchronisation below
 	HIP_TRY(hipMemcpyAsync(psz.data(), g_ctx.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipMemcpyAsync(h_status, g_ctx.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	// With DEFLATE on the device and the whole batch in one pass the host does not need sizes or status before
@@ -976,6 +1002,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	const bool one_pass = defl && g_ctx.device_deflate && (size_t)n * stride <= ((size_t)1 << 28);
 	if (!one_pass) {
 		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		drain.disarm();
 		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
 	}
 	uint8_t hdr13[13];  // core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
@@ -1005,6 +1032,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			uint32_t *osz = h_out_sizes + c0;
 			HIP_TRY(hipMemcpyAsync(osz, g_ctx.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+			drain.disarm();  // nothing queued targets this frame any more (later chunks copy into caller memory and synchronise at once)
 			HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_z0, g_ctx.ev_z1));
 			if (one_pass) {
 				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
@@ -1166,7 +1194,8 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
 	if (out_stride < zstride - 13) return fail(CCT_E_CAP, "out_stride %zu too small (need %zu)", out_stride, zstride - 13);
 	if ((rc = g_ctx.z_in.ensure((size_t)n * in_stride))) return rc;
 	if ((rc = g_ctx.z_insizes.ensure((size_t)n * 4))) return rc;
-	std::vector<uint32_t> isz(n);
+	std::vector<uint32_t> isz(n), osz(n);
+	DrainOnExit drain(g_ctx.stream);
 	HIP_TRY(hipMemsetAsync(g_ctx.z_in.p, 0, (size_t)n * in_stride, g_ctx.stream));
 	for (int i = 0; i < n; i++) {
 		isz[i] = (uint32_t)(h_offsets[i + 1] - h_offsets[i]);
@@ -1178,7 +1207,6 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
 	uint8_t hdr13[13] = {0};
 	rc = deflate_locked((const uint8_t *)g_ctx.z_in.p, in_stride, (const uint32_t *)g_ctx.z_insizes.p, n, hdr13, zstride);
 	if (rc) return rc;
-	std::vector<uint32_t> osz(n);
 	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
 	for (int i = 0; i < n; i++) {
@@ -1212,8 +1240,10 @@ int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
 	if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
 	if ((rc = g_ctx.d_payload.ensure((size_t)n * out_stride))) return rc;
 	std::vector<uint64_t> rel(n + 1);
+	std::vector<uint32_t> zst(n), osz(n);
 	for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
 	hipStream_t st = g_ctx.stream_dec;
+	DrainOnExit drain(st);
 	HIP_TRY(hipMemsetAsync((uint8_t *)g_ctx.d_arch.p + (apad > 32 ? apad - 32 : 0), 0, apad > 32 ? 48 : apad + 16, st));
 	if (abytes) HIP_TRY(hipMemcpyAsync(g_ctx.d_arch.p, h_in + a0, abytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(g_ctx.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1223,7 +1253,6 @@ int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
 	ia.out = (uint8_t *)g_ctx.d_payload.p; ia.out_stride = out_stride;
 	ia.out_sizes = (uint32_t *)g_ctx.d_sizes.p; ia.status = (uint32_t *)g_ctx.d_zstatus.p;
 	HIP_TRY(launch_inflate(ia, n, st));
-	std::vector<uint32_t> zst(n), osz(n);
 	HIP_TRY(hipMemcpyAsync(zst.data(), g_ctx.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1309,6 +1338,8 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
 	const bool dev_inflate = h0.deflate && g_ctx.device_inflate;
 	std::vector<uint32_t> dst(n), zst(n, 0);
+	std::vector<uint64_t> rel(dev_inflate ? n + 1 : 0);
+	DrainOnExit drain(g_ctx.stream_dec);  // copies into the vectors above / the caller's images must land before any return
 	if (dev_inflate) {
 		// INFLATE on the device (inflate_kernels.hip): the archive goes up as it is, payloads never touch the host
 		const uint64_t a0 = h_offsets[0], a1 = h_offsets[n];
@@ -1317,7 +1348,6 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		if ((rc = g_ctx.d_arch.ensure(apad + 16))) return rc;
 		if ((rc = g_ctx.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
 		if ((rc = g_ctx.d_zstatus.ensure((size_t)n * 4))) return rc;
-		std::vector<uint64_t> rel(n + 1);
 		for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
 		hipStream_t st = g_ctx.stream_dec;
 		const double t_inf0 = now_ms();
@@ -1409,42 +1439,6 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	}
 	return first;
 }
-
-// ---- RCCL through dlopen: the library carries no link-time dependency on librccl (573 MB) ------------------
-namespace {
-struct Rccl {
-	void *h = nullptr;
-	int (*GetUniqueId)(void *) = nullptr;
-	int (*CommInitRank)(void **, int, cct_unique_id_t, int) = nullptr;
-	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-	int (*CommDestroy)(void *) = nullptr;
-	const char *(*GetErrorString)(int) = nullptr;
-	void *comm = nullptr;
-	int rank = -1, world = 0;
-	DevBuf d_send, d_recv;
-} g_rccl;
-
-int rccl_load()
-{
-	if (g_rccl.h) return CCT_OK;
-	void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-	if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!h) return fail(CCT_E_DEVICE, "cannot load librccl: %s", dlerror());
-	g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-	g_rccl.CommInitRank = (int (*)(void **, int, cct_unique_id_t, int))dlsym(h, "ncclCommInitRank");
-	g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
-	g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-	g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-	if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) { dlclose(h); return fail(CCT_E_DEVICE, "librccl lacks an expected symbol"); }
-	g_rccl.h = h;
-	return CCT_OK;
-}
-int rccl_fail(const char *what, int rc)
-{
-	return fail(CCT_E_DEVICE, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
-}
-}  // namespace
 
 int cct_comm_unique_id(void *id128)
 {
@@ -1590,7 +1584,6 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
-	if (!strcmp(key, "deflate_ways")) { if (value < 1 || value > 8) return fail(CCT_E_ARG, "deflate_ways must be 1..8"); g_ctx.deflate_ways = value; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -1605,7 +1598,6 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "last_encode_path")) { *value = g_ctx.last_path; return CCT_OK; }
 	if (!strncmp(key, "pipe_us_k", 9) && key[9] >= '1' && key[9] <= '4') { *value = (int)(g_ctx.pipe_us[key[9] - '1'] * 10.0f); return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
-	if (!strcmp(key, "deflate_ways")) { *value = g_ctx.deflate_ways; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }

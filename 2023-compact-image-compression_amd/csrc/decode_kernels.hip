@@ -13,9 +13,10 @@
 //           a workgroup scan over role[] then gives every 16-pixel stream slot its block;
 //   pass B  parse again, now scattering each pixel to raster position O[block*bs + t].
 //
-// Streams a reference encoder cannot produce (reserved tag bytes, a jump that is not at a
-// block boundary, a jump onto a claimed block, truncation) set CCT_ST_STREAM instead of
-// replaying the reference's accidental behaviour on them; see DESIGN.md.
+// Reserved tag bytes (110xxxxx, 1111xxxx) decode as the reference decodes them: one byte, the previous pixel
+// repeats (core.py:496-520 takes no branch).  Streams a reference encoder cannot produce for which the reference
+// has no defined result (a jump that is not at a block boundary, two jump bytes in a row, a jump onto a claimed
+// block, truncation) set CCT_ST_STREAM instead of replaying its accidental behaviour on them; see DESIGN.md.
 #include "cct_internal.h"
 #include "../../include/compact_hip.h"
 
@@ -339,8 +340,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 					after_jump = true;
 					i += 1;
 				} else {
-					flags |= CCT_ST_STREAM;  // reserved tags 110xxxxx / 1111xxxx are never emitted
-					i += 1;
+					i += 1;  // reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats
 				}
 				if (is_pixel) {
 					after_jump = false;

@@ -195,7 +195,7 @@ def main():
     if os.environ.get("CCT_HOST_THREADS"):
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
-    for env, key in (("CCT_DEFLATE_WAYS", b"deflate_ways"), ("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
+    for env, key in (("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
                      ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path")):
         if os.environ.get(env):
             _ffi.check(L.cct_set_option(key, int(os.environ[env])))

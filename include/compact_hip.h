@@ -12,9 +12,17 @@
  * Conventions: plain pointers and sizes only; every function returns 0 on success or a
  * CCT_E_* code and never throws; buffers are caller-allocated; "d_" pointers are device
  * (HBM) addresses obtained from cct_dev_alloc (or any hipMalloc), "h_" pointers are host
- * addresses.  All launches go to one internal HIP stream per process; calls are
- * serialised by an internal mutex.  The library initialises HIP lazily on first use and
- * re-initialises after fork (callers such as scripts/evaluate.py:107 fork workers).
+ * addresses.  Encode-side launches go to one internal HIP stream per process and are
+ * serialised by an internal mutex; decode calls (cct_decode_batch, cct_zlib_decompress_batch)
+ * run on a second stream of their own so that one decode may overlap one encode.  The two
+ * streams are NOT ordered against each other: every host-facing call is complete when it
+ * returns (cct_dev_memset and the h2d/d2h copies included); only cct_encode_payload_dev /
+ * cct_decode_payload_dev leave work queued -- call cct_sync() before another call reads
+ * or overwrites their buffers.
+ * The library initialises HIP lazily on the first device call.  Processes that fork
+ * workers (scripts/evaluate.py:107) must fork BEFORE that call: each child then binds the
+ * GPU itself.  A child forked after its parent initialised the GPU gets CCT_E_DEVICE from
+ * every device call (ROCm cannot share a runtime across fork).
  *
  * There is NO CPU fallback: every function that computes needs a gfx950 device and fails
  * with CCT_E_DEVICE when none is usable.

@@ -227,6 +227,122 @@ def test_errors_mirror_reference(hip):
         Decoder(c4, raw[: len(raw) // 2]).decode()
 
 
+def test_reserved_tag_bytes_repeat_the_previous_pixel(hip):
+    """core.py:496-520 takes no branch for 110xxxxx / 1111xxxx: one byte is consumed and the previous pixel repeats.
+    No encoder emits them; the oracle and the HIP decoder both replay the reference on them (same pixels), in raw and
+    in deflated files, with and without mesh jumps around them."""
+    from oracle import oracle
+    from codec.core import Encoder
+    cfg = hip.default_config()
+    cfg["verbose"] = False
+    c4 = copy.deepcopy(cfg)
+    c4["encoder"]["deflate_compression"] = False
+    rng = np.random.default_rng(77)
+    img = gi.ct_phantom(1, 64)
+    raw = Encoder(c4, img).encode()
+    head, body = raw[:13], bytearray(raw[13:])
+    # (1) hand-made stream: 4096 one-pixel tokens, a third of them reserved bytes
+    toks = bytearray()
+    reserved = [0xC0, 0xC5, 0xDF, 0xF0, 0xF3, 0xFF]
+    toks += bytes([0xE3, 0x20])  # first pixel: full delta +800
+    val = 800
+    for k in range(1, 4096):
+        r = rng.integers(0, 3)
+        if r == 0:
+            toks.append(reserved[rng.integers(0, len(reserved))])
+        elif val < 2000 and (r == 1 or val < 500):
+            d = int(rng.integers(0, 0x41))  # short delta 0..64
+            toks.append(d)
+            val += d
+        else:
+            d = int(rng.integers(0xC0, 0x100))  # full delta -64..-1
+            toks += bytes([0xE0 | 0x0F, d])
+            val += d - 256
+    toks.append(59)
+    blob = head + bytes(toks)
+    want = oracle.decode(blob)
+    got = hip.decode_batch([blob], c4)[0]
+    assert got.tobytes() == want
+    flat = np.frombuffer(want, np.uint16)
+    assert len(np.unique(flat)) > 50  # the stream did something
+    # (2) a real stream (with jumps) whose short-delta bytes are overwritten by reserved bytes here and there
+    pos, k = [], 0
+    while k < len(body) - 1:
+        c = body[k]
+        if (c & 0xF0) == 0xE0:
+            k += 2
+            continue
+        if c == 0:  # a zero delta and a reserved byte both repeat the pixel: the image must not change
+            pos.append(k)
+        k += 1
+    assert len(pos) > 20
+    for k in pos[::2]:
+        body[k] = reserved[k % len(reserved)]
+    blob2 = head + bytes(body)
+    got2 = hip.decode_batch([blob2], c4)[0]
+    assert got2.tobytes() == oracle.decode(blob2)
+    assert np.array_equal(got2.reshape(img.shape), img)
+    # (3) the same bytes behind DEFLATE
+    blob3 = head[:12] + b"\x01" + zlib.compress(bytes(body), 9)
+    assert hip.decode_batch([blob3], cfg)[0].tobytes() == oracle.decode(blob3)
+    # deliberate difference that stays (DESIGN.md): two jump bytes in a row
+    from cct_hip._ffi import CorruptStreamError
+    j = next(k for k in range(len(raw) - 13) if (raw[13 + k] & 0xC0) == 0x80 and (k == 0 or (raw[13 + k - 1] & 0xF0) != 0xE0))
+    bad = bytearray(raw)
+    bad.insert(13 + j, raw[13 + j])
+    with pytest.raises(CorruptStreamError):
+        hip.decode_batch([bytes(bad)], c4)
+
+
+def test_integration_md_ctypes_stub_runs_verbatim(hip):
+    """INTEGRATION.md option B shows the binding a maintainer of the reference would add.  The code block is
+    executed here exactly as printed (the library is already loaded by the package; dlopen finds it by its soname)
+    and must produce the reference's bytes (golden fixture) and decode them back."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        text = f.read()
+    sect = text[text.index("## B."):]
+    code = sect[sect.index("```python") + len("```python"):]
+    code = code[: code.index("```")]
+    assert "def encode(cfg, image)" in code and "def decode(cfg, file_bytes, width, height)" in code
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:option-B", "exec"), ns)
+    cfg = hip.default_config()
+    done = 0
+    for name in ("slice0671", "slice3706", "noise64", "q4_block0"):
+        case = CASES[name]
+        o = case["config"]
+        if (o.get("block_size", 16), o.get("fractal", True), o.get("segmentation", True), o.get("deflate", True)) != (16, True, True, True):
+            continue
+        img = gi.build_input(case["input"])
+        got = ns["encode"](cfg, img)
+        assert len(got) == case["len"] and hashlib.sha1(got).hexdigest() == case["sha1"], name
+        want = got
+        done += 1
+        back = ns["decode"](cfg, got, img.shape[0], img.shape[1])
+        assert back == np.ascontiguousarray(img).tobytes()
+    assert done >= 2
+    with pytest.raises(ValueError, match="valid header"):
+        ns["decode"](cfg, b"nope" + want[4:], 64, 64)
+
+
+def test_fork_before_first_use_and_fork_after_init(hip):
+    """scripts/evaluate.py:107 pattern: workers forked before the first device call each bind the GPU themselves and
+    produce the same bytes as the parent; a child forked after the parent initialised the GPU is refused with
+    DeviceError (CCT_E_DEVICE).  Runs in a fresh interpreter (tests/fork_check.py): this process already owns a context."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fork_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["pool_pids"] >= 1 and not rep["parent_pid_in_pool"]
+    assert rep["pool_hashes"] == rep["parent_hashes"]
+    assert rep["late_child"][0] == "DeviceError", rep
+    assert "forked after" in rep["late_child"][2]
+    assert rep["late_exit"] == 0
+
+
 def test_encoder_decoder_files_and_preview(hip, tmp_path):
     """scripts/demo.py's flow: encode to a file, decode to a PNG preview, zero error, equal SHA-1."""
     from PIL import Image
