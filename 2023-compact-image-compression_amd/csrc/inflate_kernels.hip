@@ -11,16 +11,23 @@
 //   * lanes then restart from where their predecessor really landed until no start moves any more (lane k is
 //     final after k passes at the latest; in practice 2-3 passes), which yields the true chain of the round;
 //   * a prefix sum over output bytes gives every lane its output offset; lanes decode once more, writing
-//     literals to the output ring and LZ77 copies to a list that is then resolved in stream order
-//     (independent copies by one lane each, a dependent/overlapping one by the whole workgroup);
-//   * block headers are parsed redundantly by every lane (workgroup-uniform control flow); the canonical code
-//     tables of each block are built by wave 0 (two-level LSB-first lookup tables: 11-bit root for
-//     literal/length, 10-bit for distance, sub-tables for longer codes, base value and extra-bit count packed
-//     in the entry);
+//     literals to the output ring and LZ77 copies to a list;
+//   * block headers are parsed redundantly by every lane (workgroup-uniform control flow); the decode tables of each
+//     block are filled by gather, one lane per entry, from the canonical-code intervals (see "canonical Huffman codes"
+//     below): an 11-bit root for literal/length whose entries hold TWO literals when both codes fit, a 10-bit root for
+//     distances, no sub-tables (a longer code is decoded from the intervals directly);
+//   * a wave pays for every branch one of its lanes takes, so the symbol loop runs a few literal-only steps per general
+//     step (walk_segment);
+//   * the copies of a round are resolved a batch at a time, one lane per copy, in as many passes as the longest
+//     dependency chain of the batch; chains of run copies collapse into one pattern fill;
 //   * compressed input is staged through LDS in 4 KiB chunks, output through a 64 KiB LDS ring that
 //     is flushed to HBM as aligned 16-byte stores and Adler-summed on the way out.
 // Slices are independent, so 256 streams occupy 256 CUs at once.
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "cct_internal.h"
 #include "../../include/compact_hip.h"
@@ -32,9 +39,9 @@ constexpr int NT = 256;                       // lanes per stream
 constexpr int NWV = NT / 64;                  // waves per stream
 constexpr int INF_RING = 65536, INF_RMASK = INF_RING - 1, INF_FLUSH = 4096;
 constexpr int INF_IN = 16384, INF_CHUNK = 4096;
-constexpr int LL_BITS = 11, D_BITS = 10;
-constexpr int LL_SUB = 1280, D_SUB = 256;     // a complete sub-tree of depth 4 has >= 5 leaves: <= 16/5 entries per long code
-constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24;
+constexpr int LL_BITS = 11;
+constexpr int D_BITS = 10;
+constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24, K_TWO = 1u << 26;
 constexpr int SEG_BITS = 256;                 // compressed bits per lane and round
 constexpr int ROUND_OUT_BUDGET = 24576;       // output bytes of a round
 constexpr int LANE_OUT_CAP = 16384;           // a lane stops (and ends the round) once it has produced this much
@@ -49,14 +56,19 @@ __constant__ uint8_t c_clorder[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,
 
 constexpr int CL_BITS = 7;  // code-length codes are at most 7 bits long: one flat table
 
+// canonical code description, see "canonical Huffman codes" below
+struct CanonLds {
+	uint32_t lim[16], adj[16], offs[16];
+};
+
 struct InfShared {
 	uint8_t ring[INF_RING];
 	alignas(16) uint8_t inbuf[INF_IN];
-	// two-level decode tables (root LL_BITS / D_BITS, sub-tables for longer codes).  Entry: bits 0-3 code bits
-	// to drop, 4-7 extra bits, 8-23 value (literal, base length, base distance), 24-25 kind; bit 31 = pointer to a
-	// sub-table (bits 0-3 its index width, 8-23 its offset); 0 = no such code
+	// root decode tables (LL_BITS / D_BITS); entry layout at ll_entry() below; 0 = no code of root length or less
 	uint32_t ll_tab[1 << LL_BITS], d_tab[1 << D_BITS];
-	uint32_t ll_sub[LL_SUB], d_sub[D_SUB];
+	CanonLds ll_canon, d_canon;                 // ll_canon doubles as the code-length code's while a header is parsed
+	uint32_t ll_sent[288], d_sent[32];          // entry of every coded symbol by (length, symbol)
+	uint8_t chunkcnt[5 * 16];                   // table build: codes of every length in each chunk of 64 symbols
 	uint32_t cnt[16];
 	uint8_t cl_tab[1 << CL_BITS];               // symbol << 3 | code length, 0 = no such code
 	uint8_t lens[320];
@@ -115,37 +127,74 @@ __device__ __forceinline__ uint32_t getbits(BitReader &br, int n)
 	return v;
 }
 
-// code-length alphabet (19 symbols, <= 7 bits) from S.lens[0..19), by thread 0; S.ok = 0 if over-subscribed
+// ---- canonical Huffman codes (RFC 1951 3.2.2) as gather tables ---------------------------------------------------
+// The codes of length L are the consecutive L-bit values first[L] .. first[L] + cnt[L] - 1, handed out in symbol order,
+// and first[L + 1] = (first[L] + cnt[L]) << 1.  Written left-aligned in 15 bits (MSB = first stream bit) the code space is
+// therefore cut into consecutive intervals, one per length, in increasing order of length:
+//     a 15-bit string v opens with a code of length L  <=>  lim[L - 1] <= v < lim[L],   lim[L] = (first[L] + cnt[L]) << (15 - L)
+// and that code is the (v >> (15 - L)) - first[L]-th of its length.  With the coded symbols listed by (length, symbol) its
+// entry sits at position (v >> (15 - L)) + adj[L], adj[L] = offs[L] - first[L].  Nothing but lim[] and adj[] is needed, so
+// every entry of a lookup table is filled independently -- one lane per entry instead of one scatter loop per symbol --
+// and a code longer than the root table is decoded from lim[] / adj[] directly (no sub-tables).
+
+// per-length counts -> lim / adj / offs, by one thread; returns zlib's verdict on the set (inflate_table, inftrees.c):
+// over-subscribed, or incomplete unless it is the single one-bit code (or, for distances, no code at all)
+__device__ __forceinline__ bool canon_from_counts(const uint32_t *cnt, CanonLds &c, bool codes_type)
+{
+	int left = 1, maxlen = 0;
+	uint32_t code = 0, off = 0;
+	bool ok = true;
+	c.lim[0] = 0; c.adj[0] = 0; c.offs[0] = 0;
+	for (int len = 1; len <= 15; len++) {
+		const uint32_t cn = cnt[len];
+		left = (left << 1) - (int)cn;
+		if (left < 0) ok = false;
+		if (cn) maxlen = len;
+		c.lim[len] = ok ? (code + cn) << (15 - len) : 0u;
+		c.adj[len] = off - code; c.offs[len] = off;
+		code = (code + cn) << 1;
+		off += cn;
+	}
+	if (left > 0 && maxlen != 0 && (codes_type || maxlen != 1)) ok = false;
+	if (codes_type && maxlen == 0) ok = false;  // zlib goes on and fails at the missing end-of-block code
+	return ok;
+}
+
+// code-length alphabet (19 symbols, <= 7 bits) from S.lens[0..19); S.ok = 0 if zlib would refuse the set
 __device__ void build_cl(InfShared &S)
 {
-	for (int i = threadIdx.x; i < (1 << CL_BITS); i += NT) S.cl_tab[i] = 0;
+	if (threadIdx.x < 16) S.cnt[threadIdx.x] = 0;
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		int count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ok = 1, left = 1;
-		for (int s = 0; s < 19; s++) count[S.lens[s] & 7]++;  // 3-bit fields: lengths are 0..7
-		uint32_t next[8], c = 0;
-		next[0] = 0;
-		for (int len = 1; len <= 7; len++) {
-			left = (left << 1) - count[len];
-			if (left < 0) ok = 0;
-			c = (c + (len > 1 ? (uint32_t)count[len - 1] : 0u)) << 1;
-			next[len] = c;
+	if (threadIdx.x < 19) { const int l = S.lens[threadIdx.x] & 7; if (l) atomicAdd(&S.cnt[l], 1u); }  // 3-bit fields: lengths are 0..7
+	__syncthreads();
+	if (threadIdx.x == 0) S.ok = canon_from_counts(S.cnt, S.ll_canon, true) ? 1 : 0;
+	__syncthreads();
+	if (threadIdx.x < (1 << CL_BITS) && S.ok) {
+		const uint32_t v = (__brev((uint32_t)threadIdx.x) >> (32 - CL_BITS)) << (15 - CL_BITS);
+		int L = 0;
+		for (int len = CL_BITS; len >= 1; len--) if (v < S.ll_canon.lim[len]) L = len;
+		uint8_t e = 0;
+		if (L) {  // the want-th symbol of length L
+			const uint32_t want = (v >> (15 - L)) + S.ll_canon.adj[L] - S.ll_canon.offs[L];
+			uint32_t seen = 0;
+			int sym = 0;
+			for (int s = 0; s < 19; s++) {
+				const bool hit = (S.lens[s] & 7) == L;
+				if (hit && seen == want) sym = s;
+				seen += hit ? 1u : 0u;
+			}
+			e = (uint8_t)((sym << 3) | L);
 		}
-		for (int s = 0; ok && s < 19; s++) {
-			const int l = S.lens[s];
-			if (!l) continue;
-			const uint32_t r = __brev(next[l]++) >> (32 - l);
-			for (uint32_t k = r; k < (1u << CL_BITS); k += (1u << l)) S.cl_tab[k] = (uint8_t)((s << 3) | l);
-		}
-		S.ok = ok;
+		S.cl_tab[threadIdx.x] = e;
 	}
 	__syncthreads();
 }
 
-// decode-table entry of symbol s whose remaining code bits are `bits`
+// decode-table entries.  bits 0-3: code bits to drop (both literals of a pair), 4-7: literal: bits of the first literal;
+// length / distance: extra bits, 8-23: literals (first at 8, second at 16) or base value, 24-25 kind, 26: two literals
 __device__ __forceinline__ uint32_t ll_entry(const InfShared &S, int s, int bits)
 {
-	if (s < 256) return K_LIT | ((uint32_t)s << 8) | (uint32_t)bits;
+	if (s < 256) return K_LIT | ((uint32_t)s << 8) | ((uint32_t)bits << 4) | (uint32_t)bits;
 	if (s == 256) return K_EOB | (uint32_t)bits;
 	if (s - 257 >= 29) return 0;  // 286, 287: invalid
 	return K_LEN | ((uint32_t)S.lbase[s - 257] << 8) | ((uint32_t)S.lext[s - 257] << 4) | (uint32_t)bits;
@@ -156,98 +205,99 @@ __device__ __forceinline__ uint32_t d_entry(const InfShared &S, int s, int bits)
 	return K_LEN | ((uint32_t)S.dbase[s] << 8) | ((uint32_t)S.dext[s] << 4) | (uint32_t)bits;
 }
 
-// Two-level tables from S.lens[0..n), built by wave 0 (the other waves wait at the closing barrier);
-// S.ok = 0: over-subscribed code or sub-table overflow.
+// Lookup tables from S.lens[0..n), by the whole workgroup.  sent[]: the entry of every coded symbol, in (length, symbol)
+// order.  Root table: FB bits; a literal/length entry holds two literals when both codes fit.  S.ok = 0: zlib would
+// refuse the code lengths.
 template <bool DIST>
 __device__ void build_tables(InfShared &S, int n)
 {
-	constexpr int FB = DIST ? D_BITS : LL_BITS, SUBCAP = DIST ? D_SUB : LL_SUB;
-	uint32_t *tab = DIST ? S.d_tab : S.ll_tab, *sub = DIST ? S.d_sub : S.ll_sub;
-	const int lane = threadIdx.x & 63;
-	if (threadIdx.x < 16) S.cnt[threadIdx.x] = 0;
-	for (int i = threadIdx.x; i < (1 << FB); i += NT) tab[i] = 0;
-	for (int i = threadIdx.x; i < SUBCAP; i += NT) sub[i] = 0;
+	constexpr int FB = DIST ? D_BITS : LL_BITS;
+	uint32_t *tab = DIST ? S.d_tab : S.ll_tab;
+	uint32_t *sent = DIST ? S.d_sent : S.ll_sent;
+	CanonLds &C = DIST ? S.d_canon : S.ll_canon;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (tid < 16) S.cnt[tid] = 0;
 	__syncthreads();
-	if (threadIdx.x < 64) {
-		const uint64_t lt_mask = (1ull << lane) - 1ull;
-		bool ok = true;
-		for (int s = lane; s < n; s += 64) atomicAdd(&S.cnt[S.lens[s]], 1u);
-		__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-		uint32_t next[16];  // canonical: first code of each length
-		int left = 1;
-		uint32_t c = 0;
-		next[0] = 0;
+	for (int s = tid; s < n; s += NT) { const int l = S.lens[s]; if (l) atomicAdd(&S.cnt[l], 1u); }
+	__syncthreads();
+	if (tid == 0) S.ok = canon_from_counts(S.cnt, C, false) ? 1 : 0;
+	// entries in (length, symbol) order: chunk k = symbols [64k, 64k + 64), one wave each; rank inside the chunk by ballots,
+	// chunks before it from per-chunk counts
+	constexpr int NCH = DIST ? 1 : 5;
+	static_assert(NWV >= 4, "chunk loop below gives a wave at most two chunks");
+	uint32_t rank0 = 0, rank1 = 0;
+	int l0 = 0, l1 = 0;
+	for (int k = wave; k < NCH; k += NWV) {
+		const int s = k * 64 + lane;
+		const int l = s < n ? (int)S.lens[s] : 0;
+		uint32_t r = 0, mine = 0;
 #pragma unroll
-		for (int len = 1; len <= 15; len++) {
-			const int cn = (int)S.cnt[len];
-			left = (left << 1) - cn;
-			if (left < 0) ok = false;
-			c = (c + (len > 1 ? S.cnt[len - 1] : 0u)) << 1;
-			next[len] = c;
+		for (int b = 1; b <= 15; b++) {
+			const uint64_t bal = __ballot(l == b);
+			if (l == b) r = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+			if (lane == b) mine = (uint32_t)__popcll(bal);
 		}
-		// code of every symbol = first code of its length + number of lower symbols of that length; LSB-first reversal
-		for (int pass = 0; ok && pass < 2; pass++) {  // pass 0: sub-table widths of long codes; pass 1: entries
-			uint32_t seen[16];
-#pragma unroll
-			for (int b = 1; b <= 15; b++) seen[b] = next[b];
-			for (int s0 = 0; s0 < n; s0 += 64) {
-				const int sidx = s0 + lane;
-				const int l = sidx < n ? (int)S.lens[sidx] : 0;
-				uint32_t code = 0;
-#pragma unroll
-				for (int b = 1; b <= 15; b++) {
-					const uint64_t bal = __ballot(l == b);
-					if (l == b) code = seen[b] + (uint32_t)__popcll(bal & lt_mask);
-					seen[b] += (uint32_t)__popcll(bal);
-				}
-				const uint32_t r = l ? __brev(code) >> (32 - l) : 0u;
-				const bool wide = pass == 1 && l != 0 && l <= FB - 6;  // 64 root entries or more
-				if (l != 0) {
-					if (pass == 0) {
-						if (l > FB) atomicMax(&tab[r & ((1u << FB) - 1u)], (uint32_t)(l - FB));
-					} else if (l <= FB) {
-						// a code of l bits owns 2^(FB-l) root entries: up to 32 are written by the symbol's own lane, the
-						// short codes (64 entries and more) by the whole wave below
-						if (!wide) {
-							const uint32_t e = DIST ? d_entry(S, sidx, l) : ll_entry(S, sidx, l);
-							for (uint32_t k = r; k < (1u << FB); k += (1u << l)) tab[k] = e;
-						}
-					} else {
-						const uint32_t p = tab[r & ((1u << FB) - 1u)];
-						const uint32_t off = (p >> 8) & 0xFFFFu, kw = p & 15u;
-						const uint32_t e = DIST ? d_entry(S, sidx, l - FB) : ll_entry(S, sidx, l - FB);
-						for (uint32_t k = r >> FB; k < (1u << kw); k += (1u << (l - FB))) sub[off + k] = e;
-					}
-				}
-				for (uint64_t wm = __ballot(wide); wm; wm &= wm - 1) {  // the short codes of this chunk, one at a time
-					const int src = __ffsll((long long)wm) - 1;
-					const int wl = __shfl(l, src, 64);
-					const uint32_t wr = __shfl(r, src, 64);
-					const int ws = s0 + src;
-					const uint32_t e = DIST ? d_entry(S, ws, wl) : ll_entry(S, ws, wl);
-					for (uint32_t k = wr + ((uint32_t)lane << wl); k < (1u << FB); k += (64u << wl)) tab[k] = e;
-				}
-			}
-			__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-			if (pass == 0) {  // allocate the sub-tables: every lane owns a contiguous stretch of the root table
-				constexpr int PER = (1 << FB) / 64;
-				uint32_t sum = 0;
-				for (int i = 0; i < PER; i++) { const uint32_t kw = tab[lane * PER + i]; if (kw) sum += 1u << kw; }
-				uint32_t inc = sum;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-				if (__shfl(inc, 63, 64) > (uint32_t)SUBCAP) ok = false;
-				uint32_t off = inc - sum;
-				for (int i = 0; ok && i < PER; i++) {
-					const uint32_t kw = tab[lane * PER + i];
-					if (kw) { tab[lane * PER + i] = 0x80000000u | (off << 8) | kw; off += 1u << kw; }
-				}
-				__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-			}
-		}
-		if (lane == 0) S.ok = ok ? 1 : 0;
+		if (k == wave) { rank0 = r; l0 = l; } else { rank1 = r; l1 = l; }
+		if (lane < 16) S.chunkcnt[k * 16 + lane] = (uint8_t)mine;
 	}
 	__syncthreads();
+	if (!S.ok) { __syncthreads(); return; }
+	for (int k = wave; k < NCH; k += NWV) {
+		const int s = k * 64 + lane, l = k == wave ? l0 : l1;
+		if (l) {
+			uint32_t pos = C.offs[l] + (k == wave ? rank0 : rank1);
+			for (int q = 0; q < k; q++) pos += S.chunkcnt[q * 16 + l];
+			sent[pos] = DIST ? d_entry(S, s, l) : ll_entry(S, s, l);
+		}
+	}
+	uint32_t lim[FB + 1], adj[FB + 1];
+#pragma unroll
+	for (int len = 1; len <= FB; len++) { lim[len] = C.lim[len]; adj[len] = C.adj[len]; }
+	__syncthreads();
+	for (int idx = tid; idx < (1 << FB); idx += NT) {
+		const uint32_t rev = __brev((uint32_t)idx) >> (32 - FB);
+		const uint32_t v = rev << (15 - FB);
+		int L1 = 0;
+		uint32_t a1 = 0;
+#pragma unroll
+		for (int len = FB; len >= 1; len--) if (v < lim[len]) { L1 = len; a1 = adj[len]; }
+		uint32_t e = 0;
+		if (L1) {
+			e = sent[(v >> (15 - L1)) + a1];
+			if (!DIST && (e & (3u << 24)) == K_LIT && L1 < FB) {  // a second literal in the bits that remain?
+				const uint32_t v2 = ((rev << L1) & ((1u << FB) - 1u)) << (15 - FB);
+				int L2 = 0;
+				uint32_t a2 = 0;
+#pragma unroll
+				for (int len = FB; len >= 1; len--) if (v2 < lim[len]) { L2 = len; a2 = adj[len]; }
+				if (L2 && L1 + L2 <= FB) {
+					const uint32_t e2 = sent[(v2 >> (15 - L2)) + a2];
+					if ((e2 & (3u << 24)) == K_LIT) e = K_LIT | K_TWO | (((e2 >> 8) & 0xFFu) << 16) | (e & 0xFF00u) | ((uint32_t)L1 << 4) | (uint32_t)(L1 + L2);
+				}
+			}
+		}
+		tab[idx] = e;
+	}
+	__syncthreads();
+}
+
+// a code longer than the root table (or none at all): the interval test on lim[], see above; 0 = no such code
+template <bool DIST>
+__device__ __forceinline__ uint32_t long_code_entry(const InfShared &S, uint32_t lo)
+{
+	constexpr int FB = DIST ? D_BITS : LL_BITS;
+	const CanonLds &C = DIST ? S.d_canon : S.ll_canon;
+	const uint32_t *sent = DIST ? S.d_sent : S.ll_sent;
+	const uint32_t v = __brev(lo) >> 17;  // 15 bits, MSB = first stream bit
+	uint32_t lim[16], adj[16];
+#pragma unroll
+	for (int len = FB; len <= 15; len++) { lim[len] = C.lim[len]; adj[len] = C.adj[len]; }  // independent loads, one wait
+	int L = 0;
+	uint32_t a = 0;
+#pragma unroll
+	for (int len = 15; len > FB; len--) if (v < lim[len]) { L = len; a = adj[len]; }
+	if (v < lim[FB]) L = 0;  // a short code whose symbol is not valid (root entry 0)
+	return L ? sent[(v >> (15 - L)) + a] : 0u;
 }
 
 // per-lane bit reader over the staged input; bit positions are 32-bit offsets from the round's origin dword
@@ -273,58 +323,90 @@ __device__ __forceinline__ uint32_t lane_pos(const LaneBits &lb, uint32_t org_dw
 // Decode the symbols that START in [start, end) (one lane; bit positions relative to the round's origin dword).
 // EMIT = false: only measure (landing position, output bytes, copies).  EMIT = true: literals go to the ring
 // at `o`, copies to the list at `mi`.
+// A wave pays for every branch any of its lanes takes, and the rare symbols (copies, codes longer than the root table,
+// end of block) are rare per lane but not per wave.  So the loop runs FAST_STEPS literal-only steps (no branch: a lane
+// whose next symbol is not a literal simply does not move) for every general step.  The landing position must not depend
+// on how a lane got there (restarts compare landings): the second literal of a pair is taken only if it starts before
+// `end`, which makes the landing the first symbol boundary at or after `end` whatever the pairing.
+constexpr int FAST_STEPS = 3;
 template <bool EMIT>
 __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t &land,
-                                             uint32_t &nbytes, uint32_t &nmatch, uint32_t &flags, uint32_t o, uint32_t mi)
+                                             uint32_t &nbytes, uint32_t &nmatch, uint32_t &flags, uint32_t o, uint32_t mi,
+                                             uint32_t *steps = nullptr)
 {
+	const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
 	LaneBits lb;
 	lane_init(S, lb, org_dword, start);
+	uint32_t p = start;  // bit position of the next symbol
 	nbytes = 0; nmatch = 0; flags = 0;
-	while (lane_pos(lb, org_dword) < end) {
+	// invariant at the top of a step: more than 21 valid bits in lb.buf (a root lookup needs 11)
+	auto literal_step = [&](uint32_t e, bool live) {
+		const bool lit = live && (e & (3u << 24)) == K_LIT;
+		const uint32_t l1 = (e >> 4) & 15u;
+		const bool two = (e & K_TWO) != 0 && p + l1 < end;
+		const uint32_t used = lit ? (two ? (e & 15u) : l1) : 0u;
+		if (EMIT && lit) {
+			S.ring[(o + nbytes) & INF_RMASK] = (uint8_t)(e >> 8);
+			if (two) S.ring[(o + nbytes + 1u) & INF_RMASK] = (uint8_t)(e >> 16);
+		}
+		nbytes += lit ? (two ? 2u : 1u) : 0u;
+		lb.buf >>= used; lb.cnt -= (int)used; p += used;
+		return lit;
+	};
+	for (;;) {
+#pragma unroll
+		for (int k = 0; k < FAST_STEPS; k++) {
+			const uint32_t w = in32[lb.next & (INF_IN / 4 - 1)];  // next dword, in flight together with the table lookup
+			const uint32_t e = S.ll_tab[(uint32_t)lb.buf & ((1u << LL_BITS) - 1u)];
+			const bool take = lb.cnt <= 32;
+			lb.buf |= take ? (uint64_t)w << (lb.cnt & 63) : 0ull;
+			lb.cnt += take ? 32 : 0; lb.next += take ? 1u : 0u;
+			literal_step(e, p < end);
+		}
+		if (p >= end) break;
+		if (steps) ++*steps;
 		if (nbytes >= (uint32_t)LANE_OUT_CAP) { flags = SEG_CUT; break; }  // keeps a round inside the output ring
 		lane_refill(S, lb);
-		uint32_t lo = (uint32_t)lb.buf;
+		const uint32_t lo = (uint32_t)lb.buf;
 		uint32_t e = S.ll_tab[lo & ((1u << LL_BITS) - 1u)];
-		int used = 0;
-		if (e >> 31) { used = LL_BITS; lo >>= LL_BITS; e = S.ll_sub[((e >> 8) & 0xFFFFu) + (lo & ((1u << (e & 15u)) - 1u))]; }
-		if (e == 0) { flags = SEG_BAD; break; }
-		const uint32_t cb = e & 15u, xb = (e >> 4) & 15u;
-		const uint32_t kind = e & (3u << 24);
-		const uint32_t val = ((e >> 8) & 0xFFFFu) + ((lo >> cb) & ((1u << xb) - 1u));  // code <= 15, extra <= 5 bits: inside lo
-		used += (int)(cb + xb);
-		lb.buf >>= used; lb.cnt -= used;
-		if (kind == K_LIT) {
-			if (EMIT) S.ring[(o + nbytes) & INF_RMASK] = (uint8_t)val;
-			nbytes++;
-		} else if (kind == K_EOB) {
-			flags = SEG_EOB;
-			break;
-		} else {
+		if (e == 0) {
+			if (steps) ++steps[1];
+			e = long_code_entry<false>(S, lo);
+			if (e == 0) { flags = SEG_BAD; break; }
+		}
+		if (steps && (e & (3u << 24)) == K_LEN) ++steps[2];
+		if (!literal_step(e, true)) {
+			const uint32_t kind = e & (3u << 24);
+			if (kind == K_EOB) { lb.buf >>= (e & 15u); lb.cnt -= (int)(e & 15u); p += e & 15u; flags = SEG_EOB; break; }
+			const uint32_t cb = e & 15u, xb = (e >> 4) & 15u;
+			const uint32_t val = ((e >> 8) & 0xFFFFu) + ((lo >> cb) & ((1u << xb) - 1u));  // code <= 15, extra <= 5 bits: inside lo
+			lb.buf >>= (cb + xb); lb.cnt -= (int)(cb + xb); p += cb + xb;
 			lane_refill(S, lb);
-			uint32_t dlo = (uint32_t)lb.buf;
+			const uint32_t dlo = (uint32_t)lb.buf;
 			uint32_t de = S.d_tab[dlo & ((1u << D_BITS) - 1u)];
-			int dused = 0;
-			if (de >> 31) { dused = D_BITS; dlo >>= D_BITS; de = S.d_sub[((de >> 8) & 0xFFFFu) + (dlo & ((1u << (de & 15u)) - 1u))]; }
-			if (de == 0) { flags = SEG_BAD; break; }
+			if (de == 0) {
+				de = long_code_entry<true>(S, dlo);
+				if (de == 0) { flags = SEG_BAD; break; }
+			}
 			const uint32_t dcb = de & 15u, dxb = (de >> 4) & 15u;
 			const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((dlo >> dcb) & ((1u << dxb) - 1u));  // code <= 15, extra <= 13 bits
-			dused += (int)(dcb + dxb);
-			lb.buf >>= dused; lb.cnt -= dused;
+			lb.buf >>= (dcb + dxb); lb.cnt -= (int)(dcb + dxb); p += dcb + dxb;
 			if (EMIT) {
 				if (dist > o + nbytes) { flags = SEG_BAD; break; }  // distance too far back
 				S.mlist[mi + nmatch] = make_uint2(o + nbytes, val | ((dist - 1u) << 9));
 			}
 			nbytes += val; nmatch++;
 		}
+		lane_refill(S, lb);
 	}
-	land = lane_pos(lb, org_dword);
+	land = p;
 }
 
 // The code-length sequence of a dynamic block header (<= 316 entries, run-length coded with the 19-symbol code)
 // is the same kind of chain as the block body, so wave 0 decodes it the same way: 64 segments of CL_SEG bits,
 // restarts until no start moves, prefix sum of the entry counts, second walk that writes S.lens.  A "repeat the
 // previous length" symbol (16) writes markers that a scan resolves afterwards.
-constexpr int CL_SEG = 64;
+constexpr int CL_SEG = 16;
 constexpr uint32_t CL_BAD = 1, CL_OVER = 2;
 constexpr uint8_t CL_PREV = 0xFF;  // marker: same as the entry before (lengths are <= 15)
 
@@ -370,8 +452,18 @@ __device__ __forceinline__ int first_lane_with(InfShared &S, bool pred, int slot
 	return (int)r;
 }
 
-__global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
+// tuning runs only (CCT_INF_PROF=1): cycles per phase and event counts of every stream, written by lane 0
+enum { P_M_SETUP, P_HDR, P_TABLES, P_T_CLLENS, P_T_CL, P_T_CLWALK, P_T_LL, P_STAGE, P_WALK0, P_RESTART, P_SCAN, P_EMIT, P_MATCH, P_FLUSH, P_TOTAL, C_BLOCKS, C_ROUNDS, C_PASSES, C_MATCHES,
+       C_DEP, C_BATCH, C_LASTL, C_STEPMAX, C_STEPSUM, C_MATCHMAX, C_W0CYC, C_W0STEPS, P_N };
+#define PROF_T(slot) do { if (PROF) { const long long t_ = clock64(); prof[slot] += (uint64_t)(t_ - tprev); tprev = t_; } } while (0)
+#define PROF_C(slot, v) do { if (PROF) prof[slot] += (uint64_t)(v); } while (0)
+
+template <bool PROF>
+__global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a, uint64_t *prof_out)
 {
+	uint64_t prof[P_N] = {};
+	long long tprev = PROF ? clock64() : 0;
+	const long long tstart = tprev;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
 	InfShared &S = *reinterpret_cast<InfShared *>(smem_raw);
 	const int s = blockIdx.x;
@@ -432,9 +524,11 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 		if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) err = CCT_ST_ZLIB;  // incorrect header check
 	}
 	bool last = false;
+	PROF_T(P_HDR);
 	while (!err && !last) {
 		refill(S, br);
 		last = getbits(br, 1) != 0;
+		PROF_C(C_BLOCKS, 1);
 		const uint32_t type = getbits(br, 2);
 		if (type == 0) {  // stored
 			const int drop = br.cnt & 7;
@@ -477,7 +571,9 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 				if (tid == 0) S.lens[c_clorder[i]] = (uint8_t)v;
 			}
 			__syncthreads();
+			PROF_T(P_T_CLLENS);
 			build_cl(S);
+			PROF_T(P_T_CL);
 			if (!S.ok) { err = CCT_ST_ZLIB; break; }
 			// the code lengths of both alphabets, run-length coded; S.lens is reused after cl is built
 			{
@@ -556,12 +652,14 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			}
 			if (err) break;
 			__syncthreads();
+			PROF_T(P_T_CLWALK);
 			if (S.lens[256] == 0) { err = CCT_ST_ZLIB; break; }  // no end-of-block code
 			// distance lengths follow the literal/length lengths: move them to their own array slot first
 			uint8_t dl = 0;
 			if (tid < ndist) dl = S.lens[nlen + tid];
 			__syncthreads();
 			build_tables<false>(S, nlen);
+			PROF_T(P_T_LL);
 			if (!S.ok) { err = CCT_ST_ZLIB; break; }
 			if (tid < 32) S.lens[tid] = tid < ndist ? dl : 0;
 			__syncthreads();
@@ -570,19 +668,39 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 		}
 		// ---- symbols of this block, in speculative rounds (see the header comment)
 		uint64_t bitpos = br.bytepos * 8u - (uint64_t)br.cnt;  // true position of the next symbol
+		PROF_T(P_TABLES);
 		for (bool block_done = false; !block_done && !err;) {
 			__syncthreads();
 			if (pos - flushed >= (uint32_t)INF_FLUSH) flush_to(pos & ~(uint32_t)(INF_FLUSH - 1));
+			PROF_T(P_FLUSH);
+			PROF_C(C_ROUNDS, 1);
 			if ((bitpos >> 3) > br.nbytes + 16) { err |= CCT_ST_ZLIB; break; }  // decoding zeros past the end
 			const uint64_t need_end = ((bitpos + (uint64_t)NT * SEG_BITS) >> 3) + 32;
 			while (need_end > br.staged_end) stage_chunk(S, br);
+			PROF_T(P_STAGE);
 			const uint32_t org_dword = (uint32_t)(bitpos >> 5);      // lanes address bits relative to this dword
 			const uint32_t org_bit = (uint32_t)bitpos & 31u;
 			const uint32_t seg_end = org_bit + (uint32_t)(tid + 1) * SEG_BITS;
 			uint32_t start = org_bit + (uint32_t)tid * SEG_BITS, land, nb, nm, fl;
-			walk_segment<false>(S, org_dword, start, seg_end, land, nb, nm, fl, 0, 0);
+			uint32_t nsteps[3] = {0, 0, 0};
+			const long long tw0 = PROF ? clock64() : 0;
+			walk_segment<false>(S, org_dword, start, seg_end, land, nb, nm, fl, 0, 0, PROF ? nsteps : nullptr);
+			if (PROF) {
+				const long long tw1 = clock64();
+				uint32_t mx = nsteps[0];
+				for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+				PROF_C(C_W0CYC, tw1 - tw0); PROF_C(C_W0STEPS, mx);
+				if (tid == 0) { S.rres[0] = 0; S.rres[1] = 0; S.rres[2] = 0; }
+				__syncthreads();
+				atomicMax(&S.rres[0], nsteps[0]); atomicAdd(&S.rres[1], nsteps[0]); atomicAdd(&S.rres[2], nsteps[1]);
+				__syncthreads();
+				PROF_C(C_STEPMAX, S.rres[0]); PROF_C(C_STEPSUM, S.rres[1]); PROF_C(C_MATCHMAX, S.rres[2]);
+				__syncthreads();
+			}
+			PROF_T(P_WALK0);
 			for (;;) {  // restart from where the previous lane really landed until nothing moves
 				__syncthreads();
+				PROF_C(C_PASSES, 1);
 				S.land[tid] = land;
 				const int first = first_lane_with(S, fl != 0, 0);
 				const uint32_t pl = tid ? S.land[tid - 1] : start;
@@ -592,6 +710,7 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			}
 			// the chain is true up to the first lane that saw end-of-block or an invalid code; cut the round
 			// where the ring or the copy list would overflow (lane 0 always fits)
+			PROF_T(P_RESTART);
 			int lastl = min(first_lane_with(S, fl != 0, 1), NT - 1);
 			uint32_t cb = nb, cm = nm;  // inclusive prefix sums over the workgroup
 #pragma unroll
@@ -607,6 +726,8 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			const bool mine = tid <= lastl;
 			const uint32_t o = pos + cb - nb, mi = cm - nm;
 			uint32_t efl = 0;
+			PROF_T(P_SCAN);
+			PROF_C(C_LASTL, lastl + 1);
 			if (mine) {
 				uint32_t l2, b2, m2;
 				walk_segment<true>(S, org_dword, start, seg_end, l2, b2, m2, efl, o, mi);
@@ -614,33 +735,91 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 			if (tid == lastl) { S.rres[0] = cb; S.rres[1] = cm; S.rres[2] = land; S.rres[3] = fl; }
 			if (__syncthreads_or(mine && (efl & SEG_BAD))) { err |= CCT_ST_ZLIB; break; }
 			const uint32_t round_bytes = S.rres[0], nmatch_round = S.rres[1], round_land = S.rres[2], lfl = S.rres[3];
-			// LZ77 copies in stream order: a copy whose source ends before the first unresolved destination
-			// does not depend on the others of its batch and is done by one lane; a dependent one by everybody
-			for (uint32_t k0 = 0; k0 < nmatch_round;) {
+			PROF_T(P_EMIT);
+			PROF_C(C_MATCHES, nmatch_round);
+			// LZ77 copies of the round, NT at a time, one lane per copy.  Literals are in place already, so a copy only has
+			// to wait for the earlier copies whose destination lies inside its source (few do: most copies are 3-4 bytes
+			// from kilobytes back).  Destinations are disjoint and ascending, so those are a contiguous stretch of the list,
+			// found once by binary search; then rounds of "run what is ready" until the batch is done (the first copy that
+			// has not run is always ready).  Short copies are done by their lane, long ones by its wave.
+			// A run (a byte or a short pattern repeated for kilobytes) arrives as a chain of adjacent overlapping copies of
+			// the same distance, each reading the tail of the one before.  Such a copy continues the pattern that precedes
+			// the head of its chain, so it takes its bytes from there and waits for nothing inside the chain.
+			constexpr uint32_t SHORT_COPY = 16;
+			for (uint32_t k0 = 0; k0 < nmatch_round; k0 += NT) {
 				const uint32_t k = k0 + (uint32_t)tid;
+				const bool valid = k < nmatch_round;
 				uint2 m = make_uint2(0, 0);
-				if (k < nmatch_round) m = S.mlist[k];
+				if (valid) m = S.mlist[k];
 				const uint32_t len = m.y & 511u, dist = (m.y >> 9) + 1u;
-				const uint32_t first_dst = S.mlist[k0].x;
-				const bool indep = k < nmatch_round && len <= 16u && m.x - dist + len <= first_dst;  // long copies: everybody
-				const int nind = first_lane_with(S, !indep, 1);  // leading independent copies
-				if (tid < nind) {
-					for (uint32_t i = 0; i < len; i++) S.ring[(m.x + i) & INF_RMASK] = S.ring[(m.x - dist + i) & INF_RMASK];
-				}
-				__syncthreads();
-				k0 += (uint32_t)nind;
-				if (nind < NT && k0 < nmatch_round) {  // the next one depends on something just written
-					const uint2 dm = S.mlist[k0];
-					const uint32_t dlen = dm.y & 511u, ddist = (dm.y >> 9) + 1u;
-					if (ddist >= dlen) {
-						for (uint32_t i = tid; i < dlen; i += NT) S.ring[(dm.x + i) & INF_RMASK] = S.ring[(dm.x - ddist + i) & INF_RMASK];
-					} else {  // overlapping: the output repeats its first ddist bytes, which are already in place
-						for (uint32_t i = tid; i < dlen; i += NT) S.ring[(dm.x + i) & INF_RMASK] = S.ring[(dm.x - ddist + i % ddist) & INF_RMASK];
+				const bool periodic = dist < len;
+				uint32_t head = k, hx = m.x;
+				if (valid && periodic)
+					while (head > k0) {
+						const uint2 mm = S.mlist[head - 1];
+						const uint32_t ml = mm.y & 511u;
+						if ((mm.y >> 9) + 1u != dist || dist >= ml || mm.x + ml != hx) break;
+						hx = mm.x; head--;
 					}
-					__syncthreads();
-					k0++;
+				// bytes come from [s0, s0 + len) or, periodic, from the `dist` bytes at s0 starting at `phase`
+				const uint32_t s0 = hx - dist, s1 = periodic ? hx : s0 + len;
+				const uint32_t phase = periodic ? (m.x - hx) % dist : 0u;
+				uint32_t lo = head;  // first copy of the batch whose destination ends after s0
+				if (valid && head > k0 && s1 > S.mlist[k0].x) {
+					uint32_t a = k0, b = head;
+					while (a < b) {
+						const uint32_t mid = (a + b) >> 1;
+						const uint2 mm = S.mlist[mid];
+						if (mm.x + (mm.y & 511u) > s0) b = mid; else a = mid + 1;
+					}
+					lo = a;
 				}
+				S.land[tid] = 0;  // "has run" flags of the batch (the landing positions are not needed any more)
+				__syncthreads();
+				PROF_T(P_M_SETUP);
+				bool pending = valid;
+				do {
+					PROF_C(C_BATCH, 1);
+					bool ready = pending;
+					for (uint32_t j = lo; ready && j < head; j++) {
+						if (S.mlist[j].x >= s1) break;
+						if (!S.land[j - k0]) ready = false;
+					}
+					if (ready && len <= SHORT_COPY) {
+						if (!periodic) {  // all loads, then all stores: one LDS round trip instead of one per byte
+							uint8_t b[SHORT_COPY];
+#pragma unroll
+							for (uint32_t i = 0; i < SHORT_COPY; i++) b[i] = i < len ? S.ring[(s0 + i) & INF_RMASK] : (uint8_t)0;
+#pragma unroll
+							for (uint32_t i = 0; i < SHORT_COPY; i++) if (i < len) S.ring[(m.x + i) & INF_RMASK] = b[i];
+						} else {
+							uint32_t r = phase;
+							for (uint32_t i = 0; i < len; i++) {
+								S.ring[(m.x + i) & INF_RMASK] = S.ring[(s0 + r) & INF_RMASK];
+								if (++r == dist) r = 0;
+							}
+						}
+					}
+					for (uint64_t lm = __ballot(ready && len > SHORT_COPY); lm; lm &= lm - 1) {
+						const int src = __ffsll((long long)lm) - 1;
+						const uint32_t bx = (uint32_t)__shfl((int)m.x, src), bs = (uint32_t)__shfl((int)s0, src);
+						const uint32_t bl = (uint32_t)__shfl((int)len, src), bd = (uint32_t)__shfl((int)dist, src);
+						const uint32_t bp = (uint32_t)__shfl((int)phase, src);
+						if (bd < bl) {  // the pattern of bd bytes at bs, from phase bp on
+							uint32_t r = (bp + (uint32_t)lane) % bd;
+							const uint32_t step = 64u % bd;
+							for (uint32_t i = lane; i < bl; i += 64) {
+								S.ring[(bx + i) & INF_RMASK] = S.ring[(bs + r) & INF_RMASK];
+								r += step; if (r >= bd) r -= bd;
+							}
+						} else {
+							for (uint32_t i = lane; i < bl; i += 64) S.ring[(bx + i) & INF_RMASK] = S.ring[(bs + i) & INF_RMASK];
+						}
+					}
+					if (ready) { S.land[tid] = 1; pending = false; }  // after the bytes: LDS operations of a wave complete in order
+				} while (__syncthreads_or(pending));
 			}
+			PROF_T(P_MATCH);
 			pos += round_bytes;
 			bitpos = (uint64_t)org_dword * 32u + round_land;
 			if (lfl & SEG_BAD) { err |= CCT_ST_ZLIB; break; }
@@ -667,6 +846,10 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 	if (tid == 0) {
 		a.out_sizes[s] = (err & CCT_ST_ZLIB) ? 0u : pos;
 		a.status[s] = err;
+		if (PROF) {
+			prof[P_TOTAL] = (uint64_t)(clock64() - tstart);
+			for (int i = 0; i < P_N; i++) prof_out[(size_t)s * P_N + i] = prof[i];
+		}
 	}
 }
 
@@ -675,10 +858,34 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a)
 hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st)
 {
 	const size_t lds = sizeof(InfShared);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel),
+	static const bool want_prof = getenv("CCT_INF_PROF") != nullptr;
+	if (want_prof) {  // tuning runs only: synchronises and prints per-phase averages
+		static const char *names[P_N] = {"match_setup", "hdr", "tables(rest)", "t_cllens", "t_buildcl", "t_clwalk", "t_ll", "stage", "walk0", "restart", "scan", "emit", "match", "flush", "TOTAL", "#blocks", "#rounds",
+		                                 "#passes", "#matches", "#dependent", "#batches", "#lanes_used", "sum_round_max_gensteps", "sum_gensteps",
+		                                 "sum_long_codes", "wave0_walk_cycles", "wave0_outer_steps"};
+		uint64_t *d_prof = nullptr;
+		hipError_t e = hipMalloc(&d_prof, (size_t)n * P_N * 8);
+		if (e != hipSuccess) return e;
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(inflate_kernel<true>, dim3(n), dim3(NT), lds, st, a, d_prof);
+		std::vector<uint64_t> h((size_t)n * P_N);
+		e = hipMemcpyAsync(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		(void)hipFree(d_prof);
+		if (e != hipSuccess) return e;
+		fprintf(stderr, "[inflate prof] n=%d, per stream:", n);
+		for (int i = 0; i < P_N; i++) {
+			double sum = 0;
+			for (int s = 0; s < n; s++) sum += (double)h[(size_t)s * P_N + i];
+			fprintf(stderr, " %s=%.0f", names[i], sum / n);
+		}
+		fprintf(stderr, "\n");
+		return hipSuccess;
+	}
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<false>),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(inflate_kernel, dim3(n), dim3(NT), lds, st, a);
+	hipLaunchKernelGGL(inflate_kernel<false>, dim3(n), dim3(NT), lds, st, a, (uint64_t *)nullptr);
 	return hipGetLastError();
 }
 
