@@ -86,23 +86,57 @@ struct ShapeTables {  // everything that depends on (width, height) only; lives 
 	PipeTiles tiles;                  // host copy: travels in the kernel arguments
 };
 
-struct Context {
-	bool ready = false;
-	pid_t pid = 0;
-	int device = -1;
-	hipStream_t stream = nullptr;
-	// packed archives leave the device on their own stream from one of two buffers, after the device lock has
-	// been released: the next encode call may start its kernels while this one's files are still on the wire
+// Everything one encode batch in flight owns: stream, workspaces, the captured DEFLATE graph.  There are two of them.
+// Several kernels of the DEFLATE pass are latency-bound and leave most of the chip idle (the Huffman tree kernel runs one
+// serial heap replay per block for over a millisecond; the match kernel waits on scattered loads), so a second batch on a
+// stream of its own fills the gaps: two callers get two slots and their kernel chains interleave on the device.
+struct EncSlot {
+	std::mutex *mu = nullptr;      // slot 0: g_mu (it shares the main stream with the plumbing calls), slot 1: its own
+	hipStream_t stream = nullptr;  // slot 0: the main stream
 	// the ~25 launches of one DEFLATE pass, captured once per argument set and replayed as a graph: fewer host
 	// calls and no dispatch gaps between the kernels when a decode shares the queue processor
 	hipGraph_t z_graph = nullptr;
 	hipGraphExec_t z_graph_exec = nullptr;
 	std::vector<uint8_t> z_graph_key;
-	int use_graph = 1;
+	// packed archives leave the device on their own stream from one of two buffers, after the slot has been
+	// released: the next encode call may start its kernels while this one's files are still on the wire
 	hipStream_t stream_copy = nullptr;
 	hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
 	DevBuf z_packed2[2];
 	unsigned pack_slot = 0;
+	// encode workspaces
+	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
+	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
+	DevBuf h_stage;  // pinned host staging (payloads)
+	// device DEFLATE workspaces
+	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
+	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
+	float t_dev_deflate_ms = 0;
+	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // around the transform+pack stage
+	DevBuf *all_bufs[48];
+	int n_bufs = 0;
+	EncSlot()
+	{
+		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
+		               &e_spill, &e_tflag, &h_stage, &z_keys_in, &z_keys_out, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
+		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
+		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1]};
+		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
+		h_stage.pinned_host = true;
+	}
+	EncSlot(const EncSlot &) = delete;
+	EncSlot &operator=(const EncSlot &) = delete;
+};
+constexpr int N_ENC_SLOTS = 2;
+
+struct Context {
+	bool ready = false;
+	pid_t pid = 0;
+	int device = -1;
+	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
+	int use_graph = 1;
+	int enc_slots = N_ENC_SLOTS;  // option "encode_slots": 1 = one encode batch on the device at a time
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths, 3 staged pipeline (encode_pipe.hip) wherever it
@@ -111,26 +145,16 @@ struct Context {
 	float pipe_us[4] = {0, 0, 0, 0};
 	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel)
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
-	// encode workspaces
-	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
-	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	// decode workspaces
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
-	DevBuf h_stage;  // pinned host staging (payloads)
-	// device DEFLATE workspaces
-	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
-	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
-	bool z_tables_ready = false;
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
 	int device_inflate = 1;  // option "device_inflate": 1 = INFLATE on the device (inflate_kernels.hip, speculative lane-parallel
 	                         // decode), 0 = libz on the host thread team (same bytes; bounded by the host CPUs the process may use)
 	DevBuf d_arch, d_archoffs, d_zstatus;
-	float t_dev_deflate_ms = 0;
 	int zlib_threads = 0;
 	int wg_threads = 1024;
 	// timings of the most recent batch call (cct_last_timings)
-	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
-	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
+	hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
 	DevBuf dh_stage;  // pinned host staging of inflated payloads (decode owns it, see g_mu_dec)
 };
 
@@ -141,10 +165,13 @@ double now_ms()
 }
 
 Context g_ctx;
+EncSlot *g_enc = new EncSlot[N_ENC_SLOTS];
+void reset_ctx() { g_ctx = Context(); delete[] g_enc; g_enc = new EncSlot[N_ENC_SLOTS]; }
 // timings of the calling thread's most recent batch call (cct_last_timings): per thread, so that an encode and a
 // decode driven from two threads do not overwrite each other's numbers
 thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
-std::mutex g_mu;      // device context, stream and every HIP call
+std::mutex g_mu;      // device context, main stream (and with it encode slot 0), every plumbing call
+std::mutex g_mu1;     // encode slot 1
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
 std::mutex g_mu_dec;  // one cct_decode_batch at a time; its host INFLATE phase runs outside g_mu so that
                       // another thread's encode (device DEFLATE) can overlap with it
@@ -193,16 +220,22 @@ int ensure_ctx(int device = -1)
 		return fail(CCT_E_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
 	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_dec, hipStreamNonBlocking));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_k0));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_k1));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_z0));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_z1));
+	for (int k = 0; k < N_ENC_SLOTS; k++) {
+		EncSlot &E = g_enc[k];
+		E.mu = k == 0 ? &g_mu : &g_mu1;
+		if (k == 0) E.stream = g_ctx.stream;
+		else HIP_TRY(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreate(&E.ev_k0));
+		HIP_TRY(hipEventCreate(&E.ev_k1));
+		HIP_TRY(hipEventCreate(&E.ev_z0));
+		HIP_TRY(hipEventCreate(&E.ev_z1));
+	}
 	HIP_TRY(hipEventCreate(&g_ctx.ev_d0));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_d1));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec0));
 	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec1));
 	g_ctx.dh_stage.pinned_host = true;
-	g_ctx.h_stage.pinned_host = true;
+	HIP_TRY(deflate_init_tables());  // __constant__ tables of the DEFLATE kernels, shared by both encode slots
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
 	if (g_ctx.zlib_threads <= 0) {
@@ -525,7 +558,7 @@ void parallel_for(int n, int threads, F fn, HostTeam &team = g_team_enc)
 	team.run(n, threads, fn);
 }
 
-int encode_payload_locked(const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
+int encode_payload_locked(EncSlot &E, const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
                           int eof, uint8_t *d_payload, size_t stride, uint32_t *d_sizes, uint32_t *d_status,
                           cct_slice_stats *d_stats, uint8_t *d_roles)
 {
@@ -544,11 +577,11 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	(void)enc_lds_bytes(NB, &role_in_lds);
 	const size_t per = (size_t)n * NB;
 	int rc;
-	if (!role_in_lds) { if ((rc = g_ctx.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)g_ctx.e_role.p; }
-	if ((rc = g_ctx.e_lidx.ensure(per * 4))) return rc;
-	if ((rc = g_ctx.e_lmask.ensure(per * 8))) return rc;
-	if ((rc = g_ctx.e_lcur.ensure(per))) return rc;
-	a.ws_lidx = (uint32_t *)g_ctx.e_lidx.p; a.ws_lmask = (uint64_t *)g_ctx.e_lmask.p; a.ws_lcur = (uint8_t *)g_ctx.e_lcur.p;
+	if (!role_in_lds) { if ((rc = E.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)E.e_role.p; }
+	if ((rc = E.e_lidx.ensure(per * 4))) return rc;
+	if ((rc = E.e_lmask.ensure(per * 8))) return rc;
+	if ((rc = E.e_lcur.ensure(per))) return rc;
+	a.ws_lidx = (uint32_t *)E.e_lidx.p; a.ws_lmask = (uint64_t *)E.e_lmask.p; a.ws_lcur = (uint8_t *)E.e_lcur.p;
 	const ShapeTables *tb = nullptr;
 	if ((flags & CCT_FLAG_FRACTAL) && bs == 16 && g_ctx.use_tiles) { if ((rc = get_tables(width, height, &tb))) return rc; }
 	// the staged pipeline is the default up to 512x512 (measured: 212 / 225 us per 256 phantom / real slices against 215 / 236 us
@@ -557,112 +590,111 @@ int encode_payload_locked(const uint16_t *d_images, int n, int width, int height
 	const bool pipe_wanted = g_ctx.use_tiles == 3 || (g_ctx.use_tiles == 1 && NB <= PIPE_DEFAULT_MAX_NB);
 	if (tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && pipe_wanted && !g_ctx.dbg_skip) {
 		const int NT = tb->n_tiles;
-		if ((rc = g_ctx.e_role.ensure(per))) return rc;
-		if ((rc = g_ctx.e_toff.ensure((size_t)n * (2 * NT + 1) * 4))) return rc;
-		if ((rc = g_ctx.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
-		if ((rc = g_ctx.e_spill.ensure(per * 4))) return rc;
-		if ((rc = g_ctx.e_tflag.ensure((size_t)n * (NT + 1) * 4 + (size_t)n * NT * 4))) return rc;
+		if ((rc = E.e_role.ensure(per))) return rc;
+		if ((rc = E.e_toff.ensure((size_t)n * (2 * NT + 1) * 4))) return rc;
+		if ((rc = E.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
+		if ((rc = E.e_spill.ensure(per * 4))) return rc;
+		if ((rc = E.e_tflag.ensure((size_t)n * (NT + 1) * 4 + (size_t)n * NT * 4))) return rc;
 		PipeArgs pa{};
 		pa.e = a;
 		pa.tiles = tb->tiles; pa.ptab = tb->d_ptab; pa.ptab2 = tb->d_ptab2; pa.btab = tb->d_btab; pa.otab = tb->d_otab;
 		pa.ttab = tb->d_ttab;
 		pa.n_orient = tb->n_orient; pa.n_tiles = NT; pa.row_pitch = width;
-		pa.ssz = (uint8_t *)g_ctx.e_lcur.p; pa.mask = (uint64_t *)g_ctx.e_lmask.p; pa.roles = (uint8_t *)g_ctx.e_role.p;
-		pa.spec = (uint32_t *)g_ctx.e_lidx.p; pa.toff = (uint32_t *)g_ctx.e_toff.p; pa.pairrec = (uint8_t *)g_ctx.e_pairrec.p;
-		pa.spill_idx = (uint32_t *)g_ctx.e_spill.p;
-		pa.tflag = (uint32_t *)g_ctx.e_tflag.p; pa.tcount = pa.tflag + (size_t)n * NT; pa.tlist = pa.tcount + n;
+		pa.ssz = (uint8_t *)E.e_lcur.p; pa.mask = (uint64_t *)E.e_lmask.p; pa.roles = (uint8_t *)E.e_role.p;
+		pa.spec = (uint32_t *)E.e_lidx.p; pa.toff = (uint32_t *)E.e_toff.p; pa.pairrec = (uint8_t *)E.e_pairrec.p;
+		pa.spill_idx = (uint32_t *)E.e_spill.p;
+		pa.tflag = (uint32_t *)E.e_tflag.p; pa.tcount = pa.tflag + (size_t)n * NT; pa.tlist = pa.tcount + n;
 		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
-		HIP_TRY(launch_encode_pipe(pa, n, g_ctx.stream, &tune));
+		HIP_TRY(launch_encode_pipe(pa, n, E.stream, &tune));
 		g_ctx.last_path = 1;
 		return CCT_OK;
 	}
 	if (tb && tb->tiled) {
 		bool tile_role_in_lds = true;
 		(void)enc_tiles_lds_bytes(NB, &tile_role_in_lds);
-		if (!tile_role_in_lds) { if ((rc = g_ctx.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)g_ctx.e_role.p; }
+		if (!tile_role_in_lds) { if ((rc = E.e_role.ensure(per))) return rc; a.ws_role = (uint8_t *)E.e_role.p; }
 		else a.ws_role = nullptr;
 		TileEncArgs ta{};
 		ta.e = a;
 		ta.tile_org = tb->d_org; ta.tile_orient = tb->d_orient; ta.patterns = tb->d_pat;
 		ta.n_orient = tb->n_orient; ta.n_tiles = tb->n_tiles; ta.row_pitch = width;
-		HIP_TRY(launch_encode_tiles(ta, n, g_ctx.stream));
+		HIP_TRY(launch_encode_tiles(ta, n, E.stream));
 		g_ctx.last_path = 2;
 		return CCT_OK;
 	}
-	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, g_ctx.stream));
+	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, E.stream));
 	g_ctx.last_path = 0;
 	return CCT_OK;
 }
 
 // DEFLATE (zlib level 9 stream) of n device-resident byte strings on the device; output slice i =
-// 13 header bytes + zlib stream at d_out + i*out_stride (g_ctx.z_out), sizes in g_ctx.z_outsizes.
-int deflate_locked(const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_sizes, int n, const uint8_t header13[13],
+// 13 header bytes + zlib stream at d_out + i*out_stride (E.z_out), sizes in E.z_outsizes.
+int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_sizes, int n, const uint8_t header13[13],
                    size_t out_stride)
 {
 	if (in_stride % 256 != 0 || out_stride % 4 != 0) return fail(CCT_E_ARG, "deflate strides must be multiples of 256 / 4");
-	const size_t E = (size_t)n * in_stride;
-	if (E >= ((size_t)1 << 32)) return fail(CCT_E_ARG, "deflate batch of %zu bytes exceeds the 4 GiB sort limit; split the batch", E);
-	if (!g_ctx.z_tables_ready) { HIP_TRY(deflate_init_tables()); g_ctx.z_tables_ready = true; }
+	const size_t EB = (size_t)n * in_stride;
+	if (EB >= ((size_t)1 << 32)) return fail(CCT_E_ARG, "deflate batch of %zu bytes exceeds the 4 GiB sort limit; split the batch", EB);
 	const int max_blocks = (int)(in_stride / 16383 + 2);
 	int rc;
-	if ((rc = g_ctx.z_keys_in.ensure(E * 2))) return rc;
-	if ((rc = g_ctx.z_keys_out.ensure(E * 2))) return rc;
-	if ((rc = g_ctx.z_vals_in.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_vals_out.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_mr.ensure(E * 8))) return rc;
-	if ((rc = g_ctx.z_rec.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_sym.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_exitp.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_exitc.ensure(E * 4))) return rc;
-	if ((rc = g_ctx.z_bentry.ensure(E / 64 * 4))) return rc;
-	if ((rc = g_ctx.z_bsym.ensure(E / 64 * 4))) return rc;
-	if ((rc = g_ctx.z_small.ensure((size_t)n * (9 + 128) * 4))) return rc;
-	if ((rc = g_ctx.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
-	if ((rc = g_ctx.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
-	if ((rc = g_ctx.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
-	if ((rc = g_ctx.z_out.ensure((size_t)n * out_stride))) return rc;
-	if ((rc = g_ctx.z_outsizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = E.z_keys_in.ensure(EB * 2))) return rc;
+	if ((rc = E.z_keys_out.ensure(EB * 2))) return rc;
+	if ((rc = E.z_vals_in.ensure(EB * 4))) return rc;
+	if ((rc = E.z_vals_out.ensure(EB * 4))) return rc;
+	if ((rc = E.z_mr.ensure(EB * 8))) return rc;
+	if ((rc = E.z_rec.ensure(EB * 4))) return rc;
+	if ((rc = E.z_sym.ensure(EB * 4))) return rc;
+	if ((rc = E.z_exitp.ensure(EB * 4))) return rc;
+	if ((rc = E.z_exitc.ensure(EB * 4))) return rc;
+	if ((rc = E.z_bentry.ensure(EB / 64 * 4))) return rc;
+	if ((rc = E.z_bsym.ensure(EB / 64 * 4))) return rc;
+	if ((rc = E.z_small.ensure((size_t)n * (9 + 128) * 4))) return rc;
+	if ((rc = E.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
+	if ((rc = E.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
+	if ((rc = E.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
+	if ((rc = E.z_out.ensure((size_t)n * out_stride))) return rc;
+	if ((rc = E.z_outsizes.ensure((size_t)n * 4))) return rc;
 	// (cutting the batch into slice ranges that run concurrently on streams of their own was tried and removed: the
 	// cross-stream dependencies cost more than the overlap returned, here as in the transform+pack stage)
 	const size_t tmp = (deflate_sort_temp_bytes((size_t)n * in_stride, n) + 511) & ~(size_t)255;
-	if ((rc = g_ctx.z_sorttmp.ensure(tmp + 256))) return rc;
+	if ((rc = E.z_sorttmp.ensure(tmp + 256))) return rc;
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
-	a.keys_in = (uint16_t *)g_ctx.z_keys_in.p; a.keys_out = (uint16_t *)g_ctx.z_keys_out.p;
-	a.vals_in = (uint32_t *)g_ctx.z_vals_in.p; a.vals_out = (uint32_t *)g_ctx.z_vals_out.p;
-	uint32_t *small = (uint32_t *)g_ctx.z_small.p;
+	a.keys_in = (uint16_t *)E.z_keys_in.p; a.keys_out = (uint16_t *)E.z_keys_out.p;
+	a.vals_in = (uint32_t *)E.z_vals_in.p; a.vals_out = (uint32_t *)E.z_vals_out.p;
+	uint32_t *small = (uint32_t *)E.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
-	a.mr = g_ctx.z_mr.p; a.heavy_list = (uint32_t *)g_ctx.z_rec.p; a.sym = (uint32_t *)g_ctx.z_sym.p;
-	a.run_ends = (uint32_t *)g_ctx.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
-	a.run_len = (uint16_t *)g_ctx.z_keys_in.p;
-	a.rec32 = (uint32_t *)g_ctx.z_exitp.p; a.exit_pos = (uint32_t *)g_ctx.z_exitc.p; a.exit_cnt = (uint32_t *)g_ctx.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
-	a.blk_entry = (uint32_t *)g_ctx.z_bentry.p; a.blk_symbase = (uint32_t *)g_ctx.z_bsym.p;
-	a.blk_end = (uint32_t *)g_ctx.z_bend.p;
-	a.block_meta = (BlockMeta *)g_ctx.z_meta.p; a.block_tables = (BlockTables *)g_ctx.z_tables.p;
+	a.mr = E.z_mr.p; a.heavy_list = (uint32_t *)E.z_rec.p; a.sym = (uint32_t *)E.z_sym.p;
+	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
+	a.run_len = (uint16_t *)E.z_keys_in.p;
+	a.rec32 = (uint32_t *)E.z_exitp.p; a.exit_pos = (uint32_t *)E.z_exitc.p; a.exit_cnt = (uint32_t *)E.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
+	a.blk_entry = (uint32_t *)E.z_bentry.p; a.blk_symbase = (uint32_t *)E.z_bsym.p;
+	a.blk_end = (uint32_t *)E.z_bend.p;
+	a.block_meta = (BlockMeta *)E.z_meta.p; a.block_tables = (BlockTables *)E.z_tables.p;
 	a.max_blocks = max_blocks;
-	a.out = (uint8_t *)g_ctx.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)g_ctx.z_outsizes.p;
+	a.out = (uint8_t *)E.z_out.p; a.out_stride = out_stride; a.out_sizes = (uint32_t *)E.z_outsizes.p;
 	memcpy(a.header13, header13, 13);
 	if (g_ctx.use_graph) {
 		// whole batch on the main stream, as a graph keyed by everything the launches depend on
 		std::vector<uint8_t> key(sizeof(DeflateArgs) + sizeof(int));
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
 		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
-		if (!g_ctx.z_graph_exec || key != g_ctx.z_graph_key) {
-			if (g_ctx.z_graph_exec) { (void)hipGraphExecDestroy(g_ctx.z_graph_exec); g_ctx.z_graph_exec = nullptr; }
-			if (g_ctx.z_graph) { (void)hipGraphDestroy(g_ctx.z_graph); g_ctx.z_graph = nullptr; }
-			HIP_TRY(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
-			hipError_t le = launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream);
-			hipError_t ce = hipStreamEndCapture(g_ctx.stream, &g_ctx.z_graph);
+		if (!E.z_graph_exec || key != E.z_graph_key) {
+			if (E.z_graph_exec) { (void)hipGraphExecDestroy(E.z_graph_exec); E.z_graph_exec = nullptr; }
+			if (E.z_graph) { (void)hipGraphDestroy(E.z_graph); E.z_graph = nullptr; }
+			HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
+			hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream);
+			hipError_t ce = hipStreamEndCapture(E.stream, &E.z_graph);
 			if (le != hipSuccess) return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le));
 			HIP_TRY(ce);
-			HIP_TRY(hipGraphInstantiate(&g_ctx.z_graph_exec, g_ctx.z_graph, nullptr, nullptr, 0));
-			g_ctx.z_graph_key = key;
+			HIP_TRY(hipGraphInstantiate(&E.z_graph_exec, E.z_graph, nullptr, nullptr, 0));
+			E.z_graph_key = key;
 		}
-		HIP_TRY(hipGraphLaunch(g_ctx.z_graph_exec, g_ctx.stream));
+		HIP_TRY(hipGraphLaunch(E.z_graph_exec, E.stream));
 		return CCT_OK;
 	}
-	HIP_TRY(launch_deflate(a, n, g_ctx.z_sorttmp.p, tmp, g_ctx.stream));
+	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream));
 	return CCT_OK;
 }
 
@@ -755,11 +787,24 @@ int cct_init(int device)
 int cct_shutdown(void)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
-	if (!g_ctx.ready || g_ctx.pid != getpid()) { g_ctx = Context(); return CCT_OK; }
+	std::lock_guard<std::mutex> lk1(g_mu1);
+	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	if (!g_ctx.ready || g_ctx.pid != getpid()) { reset_ctx(); return CCT_OK; }
 	(void)hipSetDevice(g_ctx.device);
 	(void)hipStreamSynchronize(g_ctx.stream);
 	(void)hipStreamSynchronize(g_ctx.stream_dec);
-	if (g_ctx.stream_copy) (void)hipStreamSynchronize(g_ctx.stream_copy);
+	for (int k = 0; k < N_ENC_SLOTS; k++) {
+		EncSlot &E = g_enc[k];
+		if (E.stream) (void)hipStreamSynchronize(E.stream);
+		if (E.stream_copy) (void)hipStreamSynchronize(E.stream_copy);
+		if (E.z_graph_exec) (void)hipGraphExecDestroy(E.z_graph_exec);
+		if (E.z_graph) (void)hipGraphDestroy(E.z_graph);
+		for (int i = 0; i < E.n_bufs; i++) E.all_bufs[i]->release();
+		hipEvent_t evs[] = {E.ev_k0, E.ev_k1, E.ev_z0, E.ev_z1, E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};
+		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+		if (E.stream_copy) (void)hipStreamDestroy(E.stream_copy);
+		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
+	}
 	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; g_rccl.rank = -1; g_rccl.world = 0; }
 	g_rccl.d_send.release(); g_rccl.d_recv.release();
 	for (auto &kv : g_ctx.luts) {
@@ -767,24 +812,14 @@ int cct_shutdown(void)
 		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
 		for (void *p : ptrs) if (p) (void)hipFree(p);
 	}
-	if (g_ctx.z_graph_exec) (void)hipGraphExecDestroy(g_ctx.z_graph_exec);
-	if (g_ctx.z_graph) (void)hipGraphDestroy(g_ctx.z_graph);
-	DevBuf *bufs[] = {&g_ctx.e_role, &g_ctx.e_lidx, &g_ctx.e_lmask, &g_ctx.e_lcur, &g_ctx.e_images, &g_ctx.e_payload,
-	                  &g_ctx.e_sizes, &g_ctx.e_status, &g_ctx.e_stats, &g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval,
-	                  &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status, &g_ctx.d_images, &g_ctx.d_pcache, &g_ctx.h_stage,
-	                  &g_ctx.z_keys_in, &g_ctx.z_keys_out, &g_ctx.z_vals_in, &g_ctx.z_vals_out, &g_ctx.z_mr, &g_ctx.z_rec,
-	                  &g_ctx.z_exitp, &g_ctx.z_exitc, &g_ctx.z_sym, &g_ctx.z_bentry, &g_ctx.z_bsym, &g_ctx.z_small, &g_ctx.z_bend,
-	                  &g_ctx.z_meta, &g_ctx.z_tables, &g_ctx.z_sorttmp, &g_ctx.z_out, &g_ctx.z_outsizes, &g_ctx.z_in, &g_ctx.z_insizes, &g_ctx.z_packed, &g_ctx.z_packoffs, &g_ctx.z_packed2[0], &g_ctx.z_packed2[1],
-	                  &g_ctx.e_toff, &g_ctx.e_pairrec, &g_ctx.e_spill, &g_ctx.e_tflag, &g_ctx.d_arch, &g_ctx.d_archoffs, &g_ctx.d_zstatus};
+	DevBuf *bufs[] = {&g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval, &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status,
+	                  &g_ctx.d_images, &g_ctx.d_pcache, &g_ctx.d_arch, &g_ctx.d_archoffs, &g_ctx.d_zstatus, &g_ctx.dh_stage};
 	for (DevBuf *b : bufs) b->release();
-	hipEvent_t evs[] = {g_ctx.ev_k0, g_ctx.ev_k1, g_ctx.ev_d0, g_ctx.ev_d1, g_ctx.ev_z0, g_ctx.ev_z1, g_ctx.ev_k_dec0, g_ctx.ev_k_dec1,
-	                    g_ctx.ev_pack[0], g_ctx.ev_pack[1], g_ctx.ev_copied[0], g_ctx.ev_copied[1]};
+	hipEvent_t evs[] = {g_ctx.ev_d0, g_ctx.ev_d1, g_ctx.ev_k_dec0, g_ctx.ev_k_dec1};
 	for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-	g_ctx.dh_stage.release();
 	(void)hipStreamDestroy(g_ctx.stream);
 	(void)hipStreamDestroy(g_ctx.stream_dec);
-	if (g_ctx.stream_copy) (void)hipStreamDestroy(g_ctx.stream_copy);
-	g_ctx = Context();
+	reset_ctx();
 	return CCT_OK;
 }
 
@@ -878,6 +913,10 @@ int cct_sync(void)
 	int rc = ensure_ctx();
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	for (int k = 1; k < N_ENC_SLOTS; k++) {  // an encode batch call is complete when it returns; this is for symmetry only
+		std::lock_guard<std::mutex> lk1(*g_enc[k].mu);
+		HIP_TRY(hipStreamSynchronize(g_enc[k].stream));
+	}
 	return CCT_OK;
 }
 
@@ -946,7 +985,7 @@ int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int heigh
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
-	return encode_payload_locked(d_images, n, width, height, block_size, flags, eof_byte, d_payload, payload_stride,
+	return encode_payload_locked(g_enc[0], d_images, n, width, height, block_size, flags, eof_byte, d_payload, payload_stride,
 	                             d_payload_sizes, d_status, d_stats, d_roles);
 }
 
@@ -959,10 +998,26 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	// total), h_packed_offsets[n+1]; needs the device DEFLATE path (or deflate off)
 	const bool packed = h_packed_offsets != nullptr;
 	const double t_call0 = now_ms();
-	std::unique_lock<std::mutex> lk(g_mu);
-	const double t_lock0 = now_ms();
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
+	if (!(g_ctx.ready && g_ctx.pid == getpid())) {  // first use in this process: bind the device
+		std::lock_guard<std::mutex> lk0(g_mu);
+		if ((rc = ensure_ctx())) return rc;
+	}
+	// take a free encode slot (see EncSlot): the first caller gets slot 0, one that arrives while it is busy slot 1
+	std::mutex *const slot_mu[N_ENC_SLOTS] = {&g_mu, &g_mu1};
+	std::unique_lock<std::mutex> lk;
+	int slot = -1;
+	const int nslots = std::max(1, std::min(g_ctx.enc_slots, N_ENC_SLOTS));
+	while (slot < 0) {
+		for (int k = 0; k < nslots && slot < 0; k++) {
+			std::unique_lock<std::mutex> t(*slot_mu[k], std::try_to_lock);
+			if (t.owns_lock()) { lk = std::move(t); slot = k; }
+		}
+		if (slot < 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+	}
+	EncSlot &E = g_enc[slot];
+	const double t_lock0 = now_ms();
 	if ((rc = ensure_ctx())) return rc;
 	if (n == 0) return CCT_OK;
 	const size_t N = (size_t)width * height;
@@ -975,35 +1030,35 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 
 	const uint16_t *d_img = images;
 	if (!images_on_device) {
-		if ((rc = g_ctx.e_images.ensure((size_t)n * N * 2))) return rc;
-		HIP_TRY(hipMemcpyAsync(g_ctx.e_images.p, images, (size_t)n * N * 2, hipMemcpyHostToDevice, g_ctx.stream));
-		d_img = (const uint16_t *)g_ctx.e_images.p;
+		if ((rc = E.e_images.ensure((size_t)n * N * 2))) return rc;
+		HIP_TRY(hipMemcpyAsync(E.e_images.p, images, (size_t)n * N * 2, hipMemcpyHostToDevice, E.stream));
+		d_img = (const uint16_t *)E.e_images.p;
 	}
-	if ((rc = g_ctx.e_payload.ensure((size_t)n * stride))) return rc;
-	if ((rc = g_ctx.e_sizes.ensure((size_t)n * 4))) return rc;
-	if ((rc = g_ctx.e_status.ensure((size_t)n * 4))) return rc;
-	if ((rc = g_ctx.h_stage.ensure((size_t)n * stride))) return rc;
-	if ((rc = g_ctx.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
-	HIP_TRY(hipEventRecord(g_ctx.ev_k0, g_ctx.stream));
-	rc = encode_payload_locked(d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)g_ctx.e_payload.p, stride,
-	                           (uint32_t *)g_ctx.e_sizes.p, (uint32_t *)g_ctx.e_status.p,
-	                           h_stats ? (cct_slice_stats *)g_ctx.e_stats.p : nullptr, nullptr);
+	if ((rc = E.e_payload.ensure((size_t)n * stride))) return rc;
+	if ((rc = E.e_sizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = E.e_status.ensure((size_t)n * 4))) return rc;
+	if ((rc = E.h_stage.ensure((size_t)n * stride))) return rc;
+	if ((rc = E.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
+	HIP_TRY(hipEventRecord(E.ev_k0, E.stream));
+	rc = encode_payload_locked(E, d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)E.e_payload.p, stride,
+	                           (uint32_t *)E.e_sizes.p, (uint32_t *)E.e_status.p,
+	                           h_stats ? (cct_slice_stats *)E.e_stats.p : nullptr, nullptr);
 	if (rc) return rc;
-	HIP_TRY(hipEventRecord(g_ctx.ev_k1, g_ctx.stream));
+	HIP_TRY(hipEventRecord(E.ev_k1, E.stream));
 	if (h_stats)
-		HIP_TRY(hipMemcpyAsync(h_stats, g_ctx.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, g_ctx.stream));
+		HIP_TRY(hipMemcpyAsync(h_stats, E.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, E.stream));
 	std::vector<uint32_t> psz(n);
-	DrainOnExit drain(g_ctx.stream);  // until the first synchronisation below
-	HIP_TRY(hipMemcpyAsync(psz.data(), g_ctx.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-	HIP_TRY(hipMemcpyAsync(h_status, g_ctx.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+	DrainOnExit drain(E.stream);  // until the first synchronisation below
+	HIP_TRY(hipMemcpyAsync(psz.data(), E.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipMemcpyAsync(h_status, E.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
 	// With DEFLATE on the device and the whole batch in one pass the host does not need sizes or status before
 	// the DEFLATE kernels are queued (they read the sizes on the device; a payload cannot outgrow its stride):
 	// one host synchronisation less per batch.
 	const bool one_pass = defl && g_ctx.device_deflate && (size_t)n * stride <= ((size_t)1 << 28);
 	if (!one_pass) {
-		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		HIP_TRY(hipStreamSynchronize(E.stream));
 		drain.disarm();
-		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, E.ev_k0, E.ev_k1));
 	}
 	uint8_t hdr13[13];  // core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
 	hdr13[0] = (uint8_t)magic[0]; hdr13[1] = (uint8_t)magic[1]; hdr13[2] = (uint8_t)magic[2]; hdr13[3] = (uint8_t)magic[3];
@@ -1024,30 +1079,30 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		tl_deflate_ms = 0; tl_d2h_ms = 0;
 		for (int c0 = 0; c0 < n; c0 += chunk) {
 			const int nc = std::min(chunk, n - c0);
-			HIP_TRY(hipEventRecord(g_ctx.ev_z0, g_ctx.stream));
-			rc = deflate_locked((const uint8_t *)g_ctx.e_payload.p + (size_t)c0 * stride, stride,
-			                    (const uint32_t *)g_ctx.e_sizes.p + c0, nc, hdr13, zstride);
+			HIP_TRY(hipEventRecord(E.ev_z0, E.stream));
+			rc = deflate_locked(E, (const uint8_t *)E.e_payload.p + (size_t)c0 * stride, stride,
+			                    (const uint32_t *)E.e_sizes.p + c0, nc, hdr13, zstride);
 			if (rc) return rc;
-			HIP_TRY(hipEventRecord(g_ctx.ev_z1, g_ctx.stream));
+			HIP_TRY(hipEventRecord(E.ev_z1, E.stream));
 			uint32_t *osz = h_out_sizes + c0;
-			HIP_TRY(hipMemcpyAsync(osz, g_ctx.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+			HIP_TRY(hipMemcpyAsync(osz, E.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, E.stream));
+			HIP_TRY(hipStreamSynchronize(E.stream));
 			drain.disarm();  // nothing queued targets this frame any more (later chunks copy into caller memory and synchronise at once)
-			HIP_TRY(hipEventElapsedTime(&g_ctx.t_dev_deflate_ms, g_ctx.ev_z0, g_ctx.ev_z1));
+			HIP_TRY(hipEventElapsedTime(&E.t_dev_deflate_ms, E.ev_z0, E.ev_z1));
 			if (one_pass) {
-				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, g_ctx.ev_k0, g_ctx.ev_k1));
+				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, E.ev_k0, E.ev_k1));
 				for (int i = 0; i < n; i++)
 					if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
 			}
-			tl_deflate_ms += g_ctx.t_dev_deflate_ms;
+			tl_deflate_ms += E.t_dev_deflate_ms;
 			const double t_c0 = now_ms();
 			// pack the files back to back on the device, one copy into pinned memory, threaded scatter
 			std::vector<size_t> offs(nc + 1, 0);
 			for (int i = 0; i < nc; i++) offs[i + 1] = offs[i] + (((size_t)osz[i] + 15) & ~(size_t)15);
 			const size_t packed_cap = offs[nc];
-			if ((rc = g_ctx.z_packed.ensure(packed_cap + 16))) return rc;
-			if ((rc = g_ctx.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
-			if ((rc = g_ctx.h_stage.ensure(packed_cap + 16))) return rc;
+			if ((rc = E.z_packed.ensure(packed_cap + 16))) return rc;
+			if ((rc = E.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
+			if ((rc = E.h_stage.ensure(packed_cap + 16))) return rc;
 			if (packed) {  // archive layout straight into the caller's buffer
 				size_t exact = 0;
 				for (int i = 0; i < nc; i++) exact += osz[i];
@@ -1057,28 +1112,28 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				if (nc == n && is_pinned_host(h_out + at, exact)) {
 					// whole batch in one pass into a page-locked archive: pack into one of two device buffers, hand the
 					// copy to the copy stream and give the device lock back before waiting for it
-					const unsigned slot = g_ctx.pack_slot++ & 1u;
-					if (!g_ctx.stream_copy) {
-						HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream_copy, hipStreamNonBlocking));
+					const unsigned slot = E.pack_slot++ & 1u;
+					if (!E.stream_copy) {
+						HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
 						for (int k = 0; k < 2; k++) {
-							HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_pack[k], hipEventDisableTiming));
-							HIP_TRY(hipEventCreateWithFlags(&g_ctx.ev_copied[k], hipEventDisableTiming));
-							HIP_TRY(hipEventRecord(g_ctx.ev_copied[k], g_ctx.stream_copy));
+							HIP_TRY(hipEventCreateWithFlags(&E.ev_pack[k], hipEventDisableTiming));
+							HIP_TRY(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
+							HIP_TRY(hipEventRecord(E.ev_copied[k], E.stream_copy));
 						}
 					}
-					if (g_ctx.z_packed2[slot].cap < packed_cap + 16) HIP_TRY(hipEventSynchronize(g_ctx.ev_copied[slot]));  // about to be reallocated
-					if ((rc = g_ctx.z_packed2[slot].ensure(packed_cap + 16))) return rc;
-					HIP_TRY(hipStreamWaitEvent(g_ctx.stream, g_ctx.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
-					HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
-					                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed2[slot].p, 1, g_ctx.stream));
-					HIP_TRY(hipEventRecord(g_ctx.ev_pack[slot], g_ctx.stream));
-					HIP_TRY(hipStreamWaitEvent(g_ctx.stream_copy, g_ctx.ev_pack[slot], 0));
-					HIP_TRY(hipMemcpyAsync(h_out + at, g_ctx.z_packed2[slot].p, exact, hipMemcpyDeviceToHost, g_ctx.stream_copy));
-					HIP_TRY(hipEventRecord(g_ctx.ev_copied[slot], g_ctx.stream_copy));
-					hipEvent_t done = g_ctx.ev_copied[slot];
+					if (E.z_packed2[slot].cap < packed_cap + 16) HIP_TRY(hipEventSynchronize(E.ev_copied[slot]));  // about to be reallocated
+					if ((rc = E.z_packed2[slot].ensure(packed_cap + 16))) return rc;
+					HIP_TRY(hipStreamWaitEvent(E.stream, E.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
+					HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
+					                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed2[slot].p, 1, E.stream));
+					HIP_TRY(hipEventRecord(E.ev_pack[slot], E.stream));
+					HIP_TRY(hipStreamWaitEvent(E.stream_copy, E.ev_pack[slot], 0));
+					HIP_TRY(hipMemcpyAsync(h_out + at, E.z_packed2[slot].p, exact, hipMemcpyDeviceToHost, E.stream_copy));
+					HIP_TRY(hipEventRecord(E.ev_copied[slot], E.stream_copy));
+					hipEvent_t done = E.ev_copied[slot];
 					for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
 					if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
-					const float t_defl = g_ctx.t_dev_deflate_ms;
+					const float t_defl = E.t_dev_deflate_ms;
 					const double t_unlock = now_ms();
 					lk.unlock();
 					HIP_TRY(hipEventSynchronize(done));
@@ -1089,20 +1144,20 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 					tl_d2h_ms = t_tail;  // (no lock: a float for cct_last_timings; re-locking would wait for the next batch)
 					return CCT_OK;
 				}
-				HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
-				                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 1, g_ctx.stream));
+				HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
+				                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 1, E.stream));
 				double t_c1;
 				if (is_pinned_host(h_out + at, exact)) {  // the caller's archive is page-locked: no staging pass
-					HIP_TRY(hipMemcpyAsync(h_out + at, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
-					HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+					HIP_TRY(hipMemcpyAsync(h_out + at, E.z_packed.p, exact, hipMemcpyDeviceToHost, E.stream));
+					HIP_TRY(hipStreamSynchronize(E.stream));
 					t_c1 = now_ms();
 				} else {
-					HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, exact, hipMemcpyDeviceToHost, g_ctx.stream));
-					HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+					HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, exact, hipMemcpyDeviceToHost, E.stream));
+					HIP_TRY(hipStreamSynchronize(E.stream));
 					t_c1 = now_ms();
 					const int nt = std::min(g_ctx.zlib_threads, 16);
 					const size_t per = (exact + nt - 1) / nt;
-					const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
+					const uint8_t *stg = (const uint8_t *)E.h_stage.p;
 					parallel_for(nt, nt, [&](int t) {
 						const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
 						if (lo < hi) memcpy(h_out + at + lo, stg + lo, hi - lo);
@@ -1112,14 +1167,14 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				tl_d2h_ms += (float)(now_ms() - t_c0);
 				if (getenv("CCT_TRACE"))
 					fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
-					        g_ctx.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, exact);
+					        E.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, exact);
 				continue;
 			}
-			HIP_TRY(launch_pack((const uint8_t *)g_ctx.z_out.p, zstride, (const uint32_t *)g_ctx.z_outsizes.p, nc,
-			                    (uint64_t *)g_ctx.z_packoffs.p, (uint8_t *)g_ctx.z_packed.p, 0, g_ctx.stream));
-			HIP_TRY(hipMemcpyAsync(g_ctx.h_stage.p, g_ctx.z_packed.p, packed_cap, hipMemcpyDeviceToHost, g_ctx.stream));
-			HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-			const uint8_t *stg = (const uint8_t *)g_ctx.h_stage.p;
+			HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
+			                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 0, E.stream));
+			HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, packed_cap, hipMemcpyDeviceToHost, E.stream));
+			HIP_TRY(hipStreamSynchronize(E.stream));
+			const uint8_t *stg = (const uint8_t *)E.h_stage.p;
 			parallel_for(nc, std::min(g_ctx.zlib_threads, 32),
 			             [&](int i) { memcpy(h_out + (size_t)(c0 + i) * out_stride, stg + offs[i], osz[i]); });
 			tl_d2h_ms += (float)(now_ms() - t_c0);
@@ -1129,13 +1184,13 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	}
 	const double t_copy0 = now_ms();
 	// bring back only the bytes each slice produced
-	uint8_t *stage = (uint8_t *)g_ctx.h_stage.p;
+	uint8_t *stage = (uint8_t *)E.h_stage.p;
 	for (int i = 0; i < n; i++) {
 		if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
-		HIP_TRY(hipMemcpyAsync(stage + (size_t)i * stride, (uint8_t *)g_ctx.e_payload.p + (size_t)i * stride, psz[i],
-		                       hipMemcpyDeviceToHost, g_ctx.stream));
+		HIP_TRY(hipMemcpyAsync(stage + (size_t)i * stride, (uint8_t *)E.e_payload.p + (size_t)i * stride, psz[i],
+		                       hipMemcpyDeviceToHost, E.stream));
 	}
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(E.stream));
 	const double t_defl0 = now_ms();
 	tl_d2h_ms = (float)(t_defl0 - t_copy0);
 
@@ -1187,34 +1242,35 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
 	int rc = ensure_ctx();
 	if (rc) return rc;
 	if (n == 0) return CCT_OK;
+	EncSlot &E = g_enc[0];
 	size_t longest = 0;
 	for (int i = 0; i < n; i++) longest = std::max(longest, (size_t)(h_offsets[i + 1] - h_offsets[i]));
 	const size_t in_stride = (longest + 16 + 255) & ~(size_t)255;
 	const size_t zstride = (13 + compressBound((uLong)in_stride) + 63) & ~(size_t)63;
 	if (out_stride < zstride - 13) return fail(CCT_E_CAP, "out_stride %zu too small (need %zu)", out_stride, zstride - 13);
-	if ((rc = g_ctx.z_in.ensure((size_t)n * in_stride))) return rc;
-	if ((rc = g_ctx.z_insizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = E.z_in.ensure((size_t)n * in_stride))) return rc;
+	if ((rc = E.z_insizes.ensure((size_t)n * 4))) return rc;
 	std::vector<uint32_t> isz(n), osz(n);
-	DrainOnExit drain(g_ctx.stream);
-	HIP_TRY(hipMemsetAsync(g_ctx.z_in.p, 0, (size_t)n * in_stride, g_ctx.stream));
+	DrainOnExit drain(E.stream);
+	HIP_TRY(hipMemsetAsync(E.z_in.p, 0, (size_t)n * in_stride, E.stream));
 	for (int i = 0; i < n; i++) {
 		isz[i] = (uint32_t)(h_offsets[i + 1] - h_offsets[i]);
 		if (isz[i])
-			HIP_TRY(hipMemcpyAsync((uint8_t *)g_ctx.z_in.p + (size_t)i * in_stride, h_in + h_offsets[i], isz[i],
-			                       hipMemcpyHostToDevice, g_ctx.stream));
+			HIP_TRY(hipMemcpyAsync((uint8_t *)E.z_in.p + (size_t)i * in_stride, h_in + h_offsets[i], isz[i],
+			                       hipMemcpyHostToDevice, E.stream));
 	}
-	HIP_TRY(hipMemcpyAsync(g_ctx.z_insizes.p, isz.data(), (size_t)n * 4, hipMemcpyHostToDevice, g_ctx.stream));
+	HIP_TRY(hipMemcpyAsync(E.z_insizes.p, isz.data(), (size_t)n * 4, hipMemcpyHostToDevice, E.stream));
 	uint8_t hdr13[13] = {0};
-	rc = deflate_locked((const uint8_t *)g_ctx.z_in.p, in_stride, (const uint32_t *)g_ctx.z_insizes.p, n, hdr13, zstride);
+	rc = deflate_locked(E, (const uint8_t *)E.z_in.p, in_stride, (const uint32_t *)E.z_insizes.p, n, hdr13, zstride);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipMemcpyAsync(osz.data(), E.z_outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipStreamSynchronize(E.stream));
 	for (int i = 0; i < n; i++) {
 		h_out_sizes[i] = osz[i] - 13;
-		HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.z_out.p + (size_t)i * zstride + 13, osz[i] - 13,
-		                       hipMemcpyDeviceToHost, g_ctx.stream));
+		HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)E.z_out.p + (size_t)i * zstride + 13, osz[i] - 13,
+		                       hipMemcpyDeviceToHost, E.stream));
 	}
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipStreamSynchronize(E.stream));
 	return CCT_OK;
 }
 
@@ -1584,6 +1640,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -1600,6 +1657,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
+	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

@@ -791,44 +791,106 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 // by lane 0; everything around it (histogram, leaf list, bit-length statistics, code assignment) is done by
 // all 64 lanes, and the tables the serial parts index are staged in LDS (a __constant__ lookup with a
 // per-lane index is a global load: ~10x the latency of an LDS read when nothing hides it).
+// The working set decides how many blocks a CU works on at once (the serial heap replay is pure LDS latency, so
+// resident waves are what hides it): 7.3 KB lets 13 waves share the ~96 KB a CU hands out, which is one wave for every
+// block of a 256-slice batch (13 blocks per slice) in a single round.  Hence the aliasing below: the histogram
+// counters live in the heap array, the length/distance code tables of the histogram phase in dad[], codes are kept for
+// leaves only, the header bits go straight to HBM and the static code lengths are a formula.
 struct TreeScratch {  // one block's working set, in LDS
-	uint16_t freq[HEAP_SIZE], dad[HEAP_SIZE], len[HEAP_SIZE], code[HEAP_SIZE];        // literal/length tree
-	uint16_t dfreq[2 * D_CODES + 1], ddad[2 * D_CODES + 1], dlen[2 * D_CODES + 1], dcode[2 * D_CODES + 1];
-	uint16_t bfreq[2 * BL_CODES + 1], bdad[2 * BL_CODES + 1], blen[2 * BL_CODES + 1], bcode[2 * BL_CODES + 1];
+	uint16_t freq[HEAP_SIZE], dad[HEAP_SIZE], len[HEAP_SIZE], code[L_CODES + 2];      // literal/length tree
+	uint16_t dfreq[2 * D_CODES + 1], ddad[2 * D_CODES + 1], dlen[2 * D_CODES + 1], dcode[D_CODES + 2];
+	uint16_t bfreq[2 * BL_CODES + 1], bdad[2 * BL_CODES + 1], blen[2 * BL_CODES + 1], bcode[BL_CODES + 1];
 	// heap entries carry their own sort key: freq << 15 | depth << 10 | node, so that trees.c's smaller(n, m)
 	// is (e_n >> 10) <= (e_m >> 10) and one 64-bit LDS read fetches both children (freq <= 16384: 15 bits;
 	// depth <= 21 for that total weight: 5 bits; node < 573: 10 bits)
-	alignas(8) uint32_t heap[HEAP_SIZE + 1];
+	alignas(16) uint32_t heap[HEAP_SIZE + 3];
 	uint32_t bl_count[MAX_BITS + 1];
 	uint16_t next_code[MAX_BITS + 1];
-	int heap_len, heap_max, max_code, overflow;
-	uint32_t opt_len, static_len;
-	uint32_t hdr_bits[160];  // dynamic-block header: 14 + 3*19 + up to 316 * 14 bits
-	uint32_t hdr_nbits;
+	int heap_len, heap_max, max_code, overflow, lmax, dmax;
+	uint32_t opt_len, static_len, dyn_body_bits;
+	// dynamic-block header (14 + 3*19 + up to 316 * 14 bits): lane 0 keeps the open word in registers, full words go to HBM
+	uint64_t hdr_acc; uint32_t hdr_nbits; uint32_t *hdr_out;
 	// staged tables
-	uint8_t extra_l[29], extra_d[30], extra_bl[19], bl_order[19], static_llen[L_CODES + 2], length_code[256], dist_code[512];
+	uint8_t extra_l[29], extra_d[30], extra_bl[19], bl_order[19];
+	// histogram phase only (see above)
+	__device__ __forceinline__ uint32_t *hist_l() { return heap; }
+	__device__ __forceinline__ uint32_t *hist_d() { return heap + L_CODES + 2; }
+	__device__ __forceinline__ uint8_t *length_code() { return reinterpret_cast<uint8_t *>(dad); }
+	__device__ __forceinline__ uint8_t *dist_code() { return reinterpret_cast<uint8_t *>(dad) + 256; }
 };
+static_assert(sizeof(TreeScratch) <= 7380, "13 tree waves per CU need <= 7.38 KB each");
+static_assert((HEAP_SIZE + 1) * 4 >= (L_CODES + 2 + D_CODES) * 4 && HEAP_SIZE * 2 >= 768, "aliases fit");
+// tr_static_init's literal/length code lengths (trees.c:255-258)
+__device__ __forceinline__ uint32_t static_llen(int n) { return n <= 143 ? 8u : n <= 255 ? 9u : n <= 279 ? 7u : 8u; }
 
 // LDS-typed pointers: a view chosen at run time (one copy of the tree code serves all three alphabets) still
 // compiles to ds_* instructions
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct TreeView { lds_u16 *freq, *dad, *len, *code; };
 
-__device__ __forceinline__ void pqdownheap(TreeScratch &S, int k)
+// trees.c pqdownheap.  Every level is an LDS round trip on the critical path of the tree kernel, so two levels are
+// fetched at once: the pair of children and, below them, the four grandchildren (contiguous, 16-byte aligned).
+// The replay runs on one lane, but nothing in it differs between lanes: every loaded value is passed through
+// v_readfirstlane so that the compiler keeps the state in SGPRs and branches with s_cbranch instead of juggling the
+// exec mask around every `if` (that overhead, not the LDS latency, was most of the cost of a level).
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ void pqdownheap(TreeScratch &S, int k, int hl)
 {
-	const uint32_t v = S.heap[k];
-	const int hl = S.heap_len;
+	const uint32_t v = uni(S.heap[k]);
+	const uint32_t vk = v >> 10;
 	int j = k << 1;
 	while (j <= hl) {
-		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[j]);  // j is even: children j, j+1 in one read
+		uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[j]);  // j is even: children j, j+1 in one read
+		uint4 gc = *reinterpret_cast<const uint4 *>(&S.heap[min(2 * j, (HEAP_SIZE & ~3))]);  // only used when 2j <= hl
+		pr.x = uni(pr.x); pr.y = uni(pr.y);
+		gc.x = uni(gc.x); gc.y = uni(gc.y); gc.z = uni(gc.z); gc.w = uni(gc.w);
 		uint32_t e = pr.x;
-		if (j < hl && (pr.y >> 10) <= (pr.x >> 10)) { j++; e = pr.y; }
-		if ((v >> 10) <= (e >> 10)) break;
+		int c = j;
+		if (j < hl && (pr.y >> 10) <= (pr.x >> 10)) { c = j + 1; e = pr.y; }
+		if (vk <= (e >> 10)) break;
 		S.heap[k] = e;
-		k = j;
-		j <<= 1;
+		k = c;
+		j = c << 1;
+		if (j > hl) break;
+		const bool left = (c & 1) == 0;
+		const uint32_t x2 = left ? gc.x : gc.z, y2 = left ? gc.y : gc.w;
+		e = x2;
+		c = j;
+		if (j < hl && (y2 >> 10) <= (x2 >> 10)) { c = j + 1; e = y2; }
+		if (vk <= (e >> 10)) break;
+		S.heap[k] = e;
+		k = c;
+		j = c << 1;
 	}
 	S.heap[k] = v;
+}
+
+// pqdownheap(1) for a value the caller holds in a register: heap[1] is a hole, v sinks from there.  Returns what ends up
+// at heap[1], so that the caller never reads the root back.
+// All blocks of a batch replay their heaps at the same time, 13 waves to a CU, and what they compete for is instruction
+// issue: a CU has ONE scalar unit, and lane-masked control flow (every `if`, every early exit) is mostly scalar
+// instructions.  So this runs a fixed number of levels without a branch: once v has found its place the remaining
+// levels still execute, reading harmlessly and storing to the unused heap[0].
+__device__ __forceinline__ uint32_t sift_root(TreeScratch &S, uint32_t v, int hl, int levels)
+{
+	const uint32_t vk = v >> 10;
+	uint32_t rootv = v;
+	uint32_t k = 1, moving = 1;
+	for (int l = 0; l < levels; l++) {
+		const uint32_t j = k << 1;
+		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[min(j, (uint32_t)(HEAP_SIZE - 1))]);
+		const uint32_t right = (j < (uint32_t)hl && (pr.y >> 10) <= (pr.x >> 10)) ? 1u : 0u;
+		const uint32_t e = right ? pr.y : pr.x;
+		const uint32_t go = (moving && j <= (uint32_t)hl && vk > (e >> 10)) ? 1u : 0u;
+		const uint32_t put = go ? e : v;   // what the hole at k receives: the smaller child, or v (which then stays there)
+		S.heap[moving ? k : 0u] = put;
+		rootv = (moving && k == 1u) ? put : rootv;
+		k = go ? j + right : k;
+		moving = go;
+	}
+	S.heap[moving ? k : 0u] = v;
+	rootv = (moving && k == 1u) ? v : rootv;
+	return rootv;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -838,16 +900,24 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 	return v;
 }
 
-// build_tree + gen_bitlen + gen_codes (trees.c:486-700), called by the whole wave.
+// build_tree + gen_bitlen + gen_codes (trees.c:486-700) in five phases.  The heap replay and the overflow repair are
+// serial (one lane per block: dfl_tree_kernel runs them for several blocks at once, one block per lane); the phases
+// around them use all 64 lanes on one block at a time.
 // kind: 0 literal/length, 1 distance, 2 bit-length
-__device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
+__device__ __forceinline__ TreeView view_of(TreeScratch &S, int kind)
 {
-	const int lane = threadIdx.x;
-	const int elems = kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES;
-	const int max_length = kind == 2 ? MAX_BL_BITS : MAX_BITS;
-	const int base = kind == 0 ? 257 : 0;
+	if (kind == 0) return TreeView{(lds_u16 *)S.freq, (lds_u16 *)S.dad, (lds_u16 *)S.len, (lds_u16 *)S.code};
+	if (kind == 1) return TreeView{(lds_u16 *)S.dfreq, (lds_u16 *)S.ddad, (lds_u16 *)S.dlen, (lds_u16 *)S.dcode};
+	return TreeView{(lds_u16 *)S.bfreq, (lds_u16 *)S.bdad, (lds_u16 *)S.blen, (lds_u16 *)S.bcode};
+}
+__device__ __forceinline__ int elems_of(int kind) { return kind == 0 ? L_CODES : kind == 1 ? D_CODES : BL_CODES; }
+
+// (whole wave) leaves with a non-zero frequency, in symbol order: the initial heap array
+__device__ void tree_leaves(TreeScratch &S, int kind)
+{
+	const TreeView t = view_of(S, kind);
+	const int lane = threadIdx.x, elems = elems_of(kind);
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
-	// leaves with a non-zero frequency, in symbol order (the initial heap array)
 	int max_code = -1;
 	uint32_t nleaf = 0;
 	for (int n0 = 0; n0 < elems; n0 += 64) {
@@ -859,49 +929,86 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 		if (bal) max_code = n0 + 63 - __clzll((long long)bal);
 		nleaf += (uint32_t)__popcll(bal);
 	}
-	__syncthreads();
-	if (lane == 0) {
-		int n, m, node;
-		S.heap_len = (int)nleaf; S.heap_max = HEAP_SIZE;
-		while (S.heap_len < 2) {
-			node = max_code < 2 ? ++max_code : 0;
-			t.freq[node] = 1; S.opt_len--;
-			S.heap[++S.heap_len] = (1u << 15) | (uint32_t)node;
-			if (kind == 0) S.static_len -= S.static_llen[node];
-			else if (kind == 1) S.static_len -= 5;
-		}
-		for (n = S.heap_len / 2; n >= 1; n--) pqdownheap(S, n);
-		node = elems;
-		do {
-			const uint32_t en = S.heap[1];
-			S.heap[1] = S.heap[S.heap_len--]; pqdownheap(S, 1);
-			const uint32_t em = S.heap[1];
-			n = (int)(en & 1023u); m = (int)(em & 1023u);
-			S.heap[--S.heap_max] = en; S.heap[--S.heap_max] = em;
-			const uint32_t f = (en >> 15) + (em >> 15);
-			const uint32_t dn = (en >> 10) & 31u, dm = (em >> 10) & 31u;
-			const uint32_t d = (dn >= dm ? dn : dm) + 1;
-			t.freq[node] = (uint16_t)f;
-			t.dad[n] = t.dad[m] = (uint16_t)node;
-			S.heap[1] = (f << 15) | (d << 10) | (uint32_t)node;
-			node++;
-			pqdownheap(S, 1);
-		} while (S.heap_len >= 2);
-		S.heap[--S.heap_max] = S.heap[1];
-		// gen_bitlen, first loop: depth of every node, clamped (parents precede children in the sorted heap)
-		int h, bits, overflow = 0;
-		t.len[S.heap[S.heap_max] & 1023u] = 0;
-		for (h = S.heap_max + 1; h < HEAP_SIZE; h++) {
-			n = (int)(S.heap[h] & 1023u);
-			bits = t.len[t.dad[n]] + 1;
-			if (bits > max_length) { bits = max_length; overflow++; }
-			t.len[n] = (uint16_t)bits;
-		}
-		S.max_code = max_code; S.overflow = overflow;
+	if (lane == 0) { S.heap_len = (int)nleaf; S.max_code = max_code; }
+}
+
+// (one lane) the heap replay proper (trees.c:625-668)
+__device__ void tree_heap(TreeScratch &S, int kind)
+{
+	const TreeView t = view_of(S, kind);
+	int n, m, node, max_code = (int)uni((uint32_t)S.max_code);
+	int heap_len = (int)uni((uint32_t)S.heap_len), heap_max = HEAP_SIZE;  // in registers: every LDS access of this loop is on the critical path
+	while (heap_len < 2) {
+		node = max_code < 2 ? ++max_code : 0;
+		t.freq[node] = 1; S.opt_len--;
+		S.heap[++heap_len] = (1u << 15) | (uint32_t)node;
+		if (kind == 0) S.static_len -= static_llen(node);
+		else if (kind == 1) S.static_len -= 5;
 	}
+	for (n = heap_len / 2; n >= 1; n--) pqdownheap(S, n, heap_len);
+	node = elems_of(kind);
+	uint32_t top = S.heap[1];
+	do {
+		const uint32_t en = top;
+		const uint32_t lastv = S.heap[heap_len];
+		heap_len--;
+		const int levels = 31 - __clz(heap_len | 1);  // levels below the root: floor(log2(heap_len))
+		const uint32_t em = sift_root(S, lastv, heap_len, levels);
+		n = (int)(en & 1023u); m = (int)(em & 1023u);
+		S.heap[--heap_max] = en; S.heap[--heap_max] = em;
+		const uint32_t f = (en >> 15) + (em >> 15);
+		const uint32_t dn = (en >> 10) & 31u, dm = (em >> 10) & 31u;
+		const uint32_t d = (dn >= dm ? dn : dm) + 1;
+		t.freq[node] = (uint16_t)f;
+		t.dad[n] = t.dad[m] = (uint16_t)node;
+		top = sift_root(S, (f << 15) | (d << 10) | (uint32_t)node, heap_len, levels);
+		node++;
+	} while (heap_len >= 2);
+	S.heap[--heap_max] = top;
+	S.heap_len = heap_len; S.heap_max = heap_max;
+	S.max_code = max_code;
+}
+
+// (whole wave) gen_bitlen's first loop and its statistics
+__device__ void tree_depths(TreeScratch &S, int kind)
+{
+	const TreeView t = view_of(S, kind);
+	const int lane = threadIdx.x;
+	const int max_length = kind == 2 ? MAX_BL_BITS : MAX_BITS;
+	const int base = kind == 0 ? 257 : 0;
+	const int max_code = S.max_code, heap_max = S.heap_max;
+	const uint32_t root = S.heap[heap_max];
+	// trees.c:506-520: depth of every node = depth of its parent + 1, clamped to max_length; `overflow` counts the nodes
+	// that had to be clamped.  Parents precede children in the sorted tail, so trees.c does it in one serial pass; here
+	// all nodes of a level are done at once, level after level.
+	constexpr uint16_t UNKNOWN = 0xFFFF;
+	for (int h = heap_max + 1 + lane; h < HEAP_SIZE; h += 64) t.len[S.heap[h] & 1023u] = UNKNOWN;
+	if (lane == 0) t.len[root & 1023u] = 0;
 	if (lane <= MAX_BITS) S.bl_count[lane] = 0;
 	__syncthreads();
-	max_code = S.max_code;
+	for (bool again = true; again;) {
+		again = false;
+		for (int h0 = heap_max + 1; h0 < HEAP_SIZE; h0 += 64) {
+			const int h = h0 + lane;
+			bool unknown = false;
+			if (h < HEAP_SIZE) {
+				const int n = (int)(S.heap[h] & 1023u);
+				if (t.len[n] == UNKNOWN) {
+					const uint32_t ld = t.len[t.dad[n]];
+					if (ld == UNKNOWN) unknown = true;
+					else t.len[n] = (uint16_t)min(ld + 1u, (uint32_t)max_length);
+				}
+			}
+			if (__ballot(unknown)) again = true;
+		}
+		__syncthreads();
+	}
+	int overflow = 0;
+	for (int h0 = heap_max + 1; h0 < HEAP_SIZE; h0 += 64) {
+		const int h = h0 + lane;
+		const bool clamped = h < HEAP_SIZE && t.len[t.dad[S.heap[h] & 1023u]] == (uint32_t)max_length;
+		overflow += (int)__popcll(__ballot(clamped));
+	}
 	// bl_count / opt_len / static_len over the leaves (every leaf of the tree has freq != 0)
 	uint32_t o = 0, st = 0;
 	for (int n = lane; n <= max_code; n += 64) {
@@ -912,40 +1019,51 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 		uint32_t xbits = 0;
 		if (n >= base) xbits = kind == 0 ? S.extra_l[n - base] : kind == 1 ? S.extra_d[n] : S.extra_bl[n];
 		o += f * (bits + xbits);
-		if (kind == 0) st += f * ((uint32_t)S.static_llen[n] + xbits);
+		if (kind == 0) st += f * (static_llen(n) + xbits);
 		else if (kind == 1) st += f * (5u + xbits);
 	}
 	o = wave_sum(o); st = wave_sum(st);
-	__syncthreads();
-	if (lane == 0) {
-		S.opt_len += o; S.static_len += st;
-		int overflow = S.overflow;
-		if (overflow > 0) {  // rare: move leaves down until the Kraft sum fits (trees.c:540-571)
-			int bits, n, m, h = HEAP_SIZE;
-			do {
-				bits = max_length - 1;
-				while (S.bl_count[bits] == 0) bits--;
-				S.bl_count[bits]--; S.bl_count[bits + 1] += 2; S.bl_count[max_length]--;
-				overflow -= 2;
-			} while (overflow > 0);
-			for (bits = max_length; bits != 0; bits--) {
-				n = (int)S.bl_count[bits];
-				while (n != 0) {
-					m = (int)(S.heap[--h] & 1023u);
-					if (m > max_code) continue;
-					if ((uint32_t)t.len[m] != (uint32_t)bits) {
-						S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
-						t.len[m] = (uint16_t)bits;
-					}
-					n--;
+	if (lane == 0) { S.overflow = overflow; S.opt_len += o; S.static_len += st; }
+}
+
+// (one lane) gen_bitlen's overflow repair (rare) and the first code of every length
+__device__ void tree_fix(TreeScratch &S, int kind)
+{
+	const TreeView t = view_of(S, kind);
+	const int max_length = kind == 2 ? MAX_BL_BITS : MAX_BITS;
+	const int max_code = S.max_code;
+	int overflow = S.overflow;
+	if (overflow > 0) {  // move leaves down until the Kraft sum fits (trees.c:540-571)
+		int bits, n, m, h = HEAP_SIZE;
+		do {
+			bits = max_length - 1;
+			while (S.bl_count[bits] == 0) bits--;
+			S.bl_count[bits]--; S.bl_count[bits + 1] += 2; S.bl_count[max_length]--;
+			overflow -= 2;
+		} while (overflow > 0);
+		for (bits = max_length; bits != 0; bits--) {
+			n = (int)S.bl_count[bits];
+			while (n != 0) {
+				m = (int)(S.heap[--h] & 1023u);
+				if (m > max_code) continue;
+				if ((uint32_t)t.len[m] != (uint32_t)bits) {
+					S.opt_len += ((uint32_t)bits - t.len[m]) * t.freq[m];
+					t.len[m] = (uint16_t)bits;
 				}
+				n--;
 			}
 		}
-		uint32_t code = 0;
-		for (int bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; S.next_code[bits] = (uint16_t)code; }
 	}
-	__syncthreads();
-	// gen_codes: symbol n gets next_code[len] + (number of lower symbols with the same length), bit-reversed
+	uint32_t code = 0;
+	for (int bits = 1; bits <= MAX_BITS; bits++) { code = (code + S.bl_count[bits - 1]) << 1; S.next_code[bits] = (uint16_t)code; }
+}
+
+// (whole wave) gen_codes: symbol n gets next_code[len] + (number of lower symbols with the same length), bit-reversed
+__device__ void tree_codes(TreeScratch &S, int kind)
+{
+	const TreeView t = view_of(S, kind);
+	const int lane = threadIdx.x, max_code = S.max_code;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
 	uint32_t seen[MAX_BITS + 1];
 #pragma unroll
 	for (int b = 1; b <= MAX_BITS; b++) seen[b] = S.next_code[b];
@@ -961,8 +1079,6 @@ __device__ int build_tree(TreeScratch &S, const TreeView &t, int kind)
 		}
 		if (len != 0) t.code[n] = (uint16_t)(__brev(mine) >> (32 - len));
 	}
-	__syncthreads();
-	return max_code;
 }
 
 __device__ void scan_tree(TreeScratch &S, const TreeView &t, int max_code)
@@ -986,10 +1102,10 @@ __device__ void scan_tree(TreeScratch &S, const TreeView &t, int max_code)
 
 __device__ __forceinline__ void hdr_put(TreeScratch &S, uint32_t value, int length)
 {
-	const uint32_t pos = S.hdr_nbits;
-	const uint32_t w = pos >> 5, sh = pos & 31;
-	S.hdr_bits[w] |= value << sh;
-	if (sh + length > 32) S.hdr_bits[w + 1] |= value >> (32 - sh);
+	const uint32_t pos = S.hdr_nbits, sh = pos & 31;
+	uint64_t acc = S.hdr_acc | ((uint64_t)value << sh);
+	if (sh + length >= 32) { S.hdr_out[pos >> 5] = (uint32_t)acc; acc >>= 32; }
+	S.hdr_acc = acc;
 	S.hdr_nbits = pos + length;
 }
 
@@ -1013,11 +1129,15 @@ __device__ void send_tree(TreeScratch &S, const TreeView &t, int max_code)
 	}
 }
 
-// one wave per (slice, block): histogram + trees (trees.c _tr_flush_block)
+// One wave per TREE_BLOCKS consecutive blocks of a slice: histograms + trees (trees.c _tr_flush_block).  The serial
+// parts of a block (heap replay, run-length scan of the code lengths, header bits) keep one lane busy and cost the wave a
+// full instruction stream each; with four blocks per wave, lanes 0..3 run them side by side and the instruction count per
+// block drops accordingly.  The parallel parts take the blocks in turn.
+constexpr int TREE_BLOCKS = 1;
 __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 {
-	__shared__ TreeScratch S;
-	const int s = blockIdx.y, m = blockIdx.x;
+	__shared__ TreeScratch S4[TREE_BLOCKS];
+	const int s = blockIdx.y, m0 = blockIdx.x * TREE_BLOCKS, lane = threadIdx.x;
 	const uint32_t T = a.total_syms[s];
 	const uint32_t L = a.in_sizes[s];
 	// number of blocks: one flush per 16383 tallied symbols inside the loop, plus the final flush
@@ -1025,66 +1145,105 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 	if (T % BLOCK_SYMS == 0 && nfull > 0 && a.postloop_lit[s]) nfull--;  // the post-loop literal never flushes
 	const uint32_t nblocks = nfull + 1;
 	BlockMeta *meta = a.block_meta + (size_t)s * a.max_blocks;
-	if ((uint32_t)m >= nblocks) return;
-	const bool last = (uint32_t)m == nblocks - 1;
-	const uint32_t first = (uint32_t)m * BLOCK_SYMS;
-	const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
-	const uint32_t *sym = a.sym + (size_t)s * a.in_stride + first;
+	if ((uint32_t)m0 >= nblocks) return;
+	const int nb = (int)min((uint32_t)TREE_BLOCKS, nblocks - (uint32_t)m0);
 	const uint32_t *bend = a.blk_end + (size_t)s * a.max_blocks;
-	const uint32_t in_begin = m == 0 ? 0u : bend[m - 1];
-	const uint32_t in_end = last ? L : bend[m];
+	const bool owner = lane < nb;  // lane q runs the serial parts of block m0 + q
+#ifdef CCT_TREE_PROF  // tuning builds only: phase times of one workgroup
+	long long tp[16]; int tpi = 0;
+#define TREE_STAMP() do { if (tpi < 16) tp[tpi++] = clock64(); } while (0)
+#else
+#define TREE_STAMP() do {} while (0)
+#endif
+	TREE_STAMP();
 
-	for (int i = threadIdx.x; i < HEAP_SIZE; i += blockDim.x) { S.freq[i] = 0; S.len[i] = 0; S.dad[i] = 0; S.code[i] = 0; }
-	for (int i = threadIdx.x; i < 2 * D_CODES + 1; i += blockDim.x) { S.dfreq[i] = 0; S.dlen[i] = 0; S.ddad[i] = 0; S.dcode[i] = 0; }
-	for (int i = threadIdx.x; i < 2 * BL_CODES + 1; i += blockDim.x) { S.bfreq[i] = 0; S.blen[i] = 0; S.bdad[i] = 0; S.bcode[i] = 0; }
-	for (int i = threadIdx.x; i < 160; i += blockDim.x) S.hdr_bits[i] = 0;
-	for (int i = threadIdx.x; i < 512; i += blockDim.x) S.dist_code[i] = c_dist_code[i];
-	for (int i = threadIdx.x; i < 256; i += blockDim.x) S.length_code[i] = c_length_code[i];
-	for (int i = threadIdx.x; i < L_CODES + 2; i += blockDim.x) S.static_llen[i] = c_static_llen[i];
-	if (threadIdx.x < 29) S.extra_l[threadIdx.x] = c_extra_lbits[threadIdx.x];
-	if (threadIdx.x < 30) S.extra_d[threadIdx.x] = c_extra_dbits[threadIdx.x];
-	if (threadIdx.x < 19) { S.extra_bl[threadIdx.x] = c_extra_blbits[threadIdx.x]; S.bl_order[threadIdx.x] = c_bl_order[threadIdx.x]; }
-	__shared__ uint32_t hl[L_CODES], hd[D_CODES];
-	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) hl[i] = 0;
-	if (threadIdx.x < D_CODES) hd[threadIdx.x] = 0;
-	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < nsym; i += blockDim.x) {
-		const uint32_t v = sym[i];
-		const uint32_t dist = v >> 16, lc = v & 0xFFu;
-		if (dist == 0) atomicAdd(&hl[lc], 1u);
-		else {
-			const uint32_t d1 = dist - 1;
-			atomicAdd(&hl[S.length_code[lc] + 256 + 1], 1u);
-			atomicAdd(&hd[d1 < 256 ? S.dist_code[d1] : S.dist_code[256 + (d1 >> 7)]], 1u);
+	for (int q = 0; q < nb; q++) {
+		TreeScratch &S = S4[q];
+		const int m = m0 + q;
+		const bool last = (uint32_t)m == nblocks - 1;
+		const uint32_t first = (uint32_t)m * BLOCK_SYMS;
+		const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
+		const uint32_t *sym = a.sym + (size_t)s * a.in_stride + first;
+		BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m);
+		for (int i = lane; i < HEAP_SIZE; i += 64) { S.freq[i] = 0; S.len[i] = 0; }
+		for (int i = lane; i < L_CODES + 2; i += 64) S.code[i] = 0;
+		for (int i = lane; i < 2 * D_CODES + 1; i += 64) { S.dfreq[i] = 0; S.dlen[i] = 0; S.ddad[i] = 0; }
+		for (int i = lane; i < D_CODES + 2; i += 64) S.dcode[i] = 0;
+		for (int i = lane; i < 2 * BL_CODES + 1; i += 64) { S.bfreq[i] = 0; S.blen[i] = 0; S.bdad[i] = 0; }
+		for (int i = lane; i < BL_CODES + 1; i += 64) S.bcode[i] = 0;
+		uint8_t *length_code = S.length_code(), *dist_code = S.dist_code();
+		for (int i = lane; i < 512; i += 64) dist_code[i] = c_dist_code[i];
+		for (int i = lane; i < 256; i += 64) length_code[i] = c_length_code[i];
+		if (lane < 29) S.extra_l[lane] = c_extra_lbits[lane];
+		if (lane < 30) S.extra_d[lane] = c_extra_dbits[lane];
+		if (lane < 19) { S.extra_bl[lane] = c_extra_blbits[lane]; S.bl_order[lane] = c_bl_order[lane]; }
+		uint32_t *hl = S.hist_l(), *hd = S.hist_d();
+		for (int i = lane; i < L_CODES; i += 64) hl[i] = 0;
+		if (lane < D_CODES) hd[lane] = 0;
+		__syncthreads();
+		for (uint32_t i0 = 0; i0 < nsym; i0 += 64 * 8) {  // eight loads in flight: one wave per block, nothing else hides HBM latency
+			uint32_t v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < nsym ? sym[i] : 0xFFFFFFFFu; }
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				if (v[k] == 0xFFFFFFFFu) continue;  // (a symbol never looks like this: length codes are <= 255)
+				const uint32_t dist = v[k] >> 16, lc = v[k] & 0xFFu;
+				if (dist == 0) atomicAdd(&hl[lc], 1u);
+				else {
+					const uint32_t d1 = dist - 1;
+					atomicAdd(&hl[length_code[lc] + 256 + 1], 1u);
+					atomicAdd(&hd[d1 < 256 ? dist_code[d1] : dist_code[256 + (d1 >> 7)]], 1u);
+				}
+			}
 		}
+		__syncthreads();
+		for (int i = lane; i < L_CODES; i += 64) S.freq[i] = (uint16_t)hl[i];
+		if (lane < D_CODES) S.dfreq[lane] = (uint16_t)hd[lane];
+		if (lane == 0) { S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0; S.hdr_acc = 0; S.hdr_out = bt->hdr_bits; }
+		__syncthreads();
+		if (lane == 0) S.freq[END_BLOCK] = 1;
+		for (int i = lane; i < HEAP_SIZE; i += 64) S.dad[i] = 0;  // held the code tables of the histogram
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) S.freq[i] = (uint16_t)hl[i];
-	if (threadIdx.x < D_CODES) S.dfreq[threadIdx.x] = (uint16_t)hd[threadIdx.x];
-	if (threadIdx.x == 0) { S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0; }
-	__syncthreads();
-	if (threadIdx.x == 0) S.freq[END_BLOCK] = 1;
-	__syncthreads();
-	const TreeView lt{(lds_u16 *)S.freq, (lds_u16 *)S.dad, (lds_u16 *)S.len, (lds_u16 *)S.code};
-	const TreeView dt{(lds_u16 *)S.dfreq, (lds_u16 *)S.ddad, (lds_u16 *)S.dlen, (lds_u16 *)S.dcode};
-	const TreeView btv{(lds_u16 *)S.bfreq, (lds_u16 *)S.bdad, (lds_u16 *)S.blen, (lds_u16 *)S.bcode};
-	int lmax = 0, dmax = 0;
-	uint32_t dyn_body_bits = 0;
+	TREE_STAMP();
 #pragma unroll 1
 	for (int kind = 0; kind < 3; kind++) {  // literal/length, distance, then the bit-length tree over both
 		if (kind == 2) {
-			dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
-			__syncthreads();
-			if (threadIdx.x == 0) {
+			if (owner) {
+				TreeScratch &S = S4[lane];
+				S.dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
 #pragma unroll 1
-				for (int w = 0; w < 2; w++) scan_tree(S, w ? dt : lt, w ? dmax : lmax);
+				for (int w = 0; w < 2; w++) scan_tree(S, view_of(S, w), w ? S.dmax : S.lmax);
 			}
 			__syncthreads();
 		}
-		const int mc = build_tree(S, kind == 0 ? lt : kind == 1 ? dt : btv, kind);
-		if (kind == 0) lmax = mc; else if (kind == 1) dmax = mc;
+		for (int q = 0; q < nb; q++) tree_leaves(S4[q], kind);
+		__syncthreads();
+		TREE_STAMP();
+		if (owner) tree_heap(S4[lane], kind);
+		__syncthreads();
+		TREE_STAMP();
+		for (int q = 0; q < nb; q++) tree_depths(S4[q], kind);
+		__syncthreads();
+		if (owner) {
+			tree_fix(S4[lane], kind);
+			if (kind == 0) S4[lane].lmax = S4[lane].max_code; else if (kind == 1) S4[lane].dmax = S4[lane].max_code;
+		}
+		__syncthreads();
+		for (int q = 0; q < nb; q++) tree_codes(S4[q], kind);
+		__syncthreads();
+		TREE_STAMP();
 	}
-	if (threadIdx.x == 0) {
+	if (owner) {
+		TreeScratch &S = S4[lane];
+		const int m = m0 + lane;
+		const bool last = (uint32_t)m == nblocks - 1;
+		const uint32_t first = (uint32_t)m * BLOCK_SYMS;
+		const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
+		const uint32_t in_begin = m == 0 ? 0u : bend[m - 1];
+		const uint32_t in_end = last ? L : bend[m];
+		const int lmax = S.lmax, dmax = S.dmax;
 		int max_blindex;
 		for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
 			if (S.blen[S.bl_order[max_blindex]] != 0) break;
@@ -1108,19 +1267,30 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 			hdr_put(S, (uint32_t)(max_blindex + 1 - 4), 4);
 			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[S.bl_order[rank]], 3);
 #pragma unroll 1
-			for (int w = 0; w < 2; w++) send_tree(S, w ? dt : lt, w ? dmax : lmax);
+			for (int w = 0; w < 2; w++) send_tree(S, view_of(S, w), w ? dmax : lmax);
+			if (S.hdr_nbits & 31u) S.hdr_out[S.hdr_nbits >> 5] = (uint32_t)S.hdr_acc;  // the open word
 			bm.hdr_nbits = S.hdr_nbits;
-			bm.body_bits = dyn_body_bits;
+			bm.body_bits = S.dyn_body_bits;
 		}
 		meta[m] = bm;
 		if (m == 0) a.n_blocks[s] = nblocks;
 	}
 	__syncthreads();
-	// publish code tables and header bits for the emit kernel
-	BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m);
-	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) { bt->lcode[i] = S.code[i]; bt->llen[i] = (uint8_t)S.len[i]; }
-	if (threadIdx.x < D_CODES) { bt->dcode[threadIdx.x] = S.dcode[threadIdx.x]; bt->dlen[threadIdx.x] = (uint8_t)S.dlen[threadIdx.x]; }
-	for (int i = threadIdx.x; i < 160; i += blockDim.x) bt->hdr_bits[i] = S.hdr_bits[i];
+	TREE_STAMP();
+#ifdef CCT_TREE_PROF
+	if (s == 0 && m0 == 0 && lane == 0) {
+		printf("[tree prof] nb=%d:", nb);
+		for (int i = 1; i < tpi; i++) printf(" %lld", tp[i] - tp[i - 1]);
+		printf("  (hist | leaves0 heap0 rest0 | scan+leaves1 heap1 rest1 | scan_tree+leaves2 heap2 rest2 | final)\n");
+	}
+#endif
+	// publish the code tables for the emit kernel
+	for (int q = 0; q < nb; q++) {
+		TreeScratch &S = S4[q];
+		BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m0 + q);
+		for (int i = lane; i < L_CODES; i += 64) { bt->lcode[i] = S.code[i]; bt->llen[i] = (uint8_t)S.len[i]; }
+		if (lane < D_CODES) { bt->dcode[lane] = S.dcode[lane]; bt->dlen[lane] = (uint8_t)S.dlen[lane]; }
+	}
 }
 
 // ------------------------------------------------------------------ 5. Adler-32 + layout
@@ -1426,7 +1596,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(dfl_tree_kernel, dim3(a.max_blocks, n), dim3(64), 0, st, a);  // one wave: the tree build is one lane, more blocks per CU in flight
+	hipLaunchKernelGGL(dfl_tree_kernel, dim3((a.max_blocks + TREE_BLOCKS - 1) / TREE_BLOCKS, n), dim3(64), 0, st, a);
 	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_emit_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);

@@ -196,7 +196,8 @@ def main():
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
     for env, key in (("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
-                     ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path")):
+                     ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path"),
+                     ("CCT_ENCODE_SLOTS", b"encode_slots")):
         if os.environ.get(env):
             _ffi.check(L.cct_set_option(key, int(os.environ[env])))
     dev_deflate, dev_inflate = C.c_int(0), C.c_int(0)
