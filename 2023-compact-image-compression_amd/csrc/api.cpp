@@ -98,6 +98,10 @@ struct EncSlot {
 	hipGraph_t z_graph = nullptr;
 	hipGraphExec_t z_graph_exec = nullptr;
 	std::vector<uint8_t> z_graph_key;
+	// the memset + four launches of the transform+pack pipeline, likewise (a few argument sets: callers rotate batches)
+	struct PipeGraph { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+	std::vector<PipeGraph> p_graphs;
+	uint64_t p_clock = 0;
 	// packed archives leave the device on their own stream from one of two buffers, after the slot has been
 	// released: the next encode call may start its kernels while this one's files are still on the wire
 	hipStream_t stream_copy = nullptr;
@@ -558,7 +562,7 @@ void parallel_for(int n, int threads, F fn, HostTeam &team = g_team_enc)
 	team.run(n, threads, fn);
 }
 
-int encode_payload_locked(EncSlot &E, const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
+int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, int n, int width, int height, int bs, uint32_t flags,
                           int eof, uint8_t *d_payload, size_t stride, uint32_t *d_sizes, uint32_t *d_status,
                           cct_slice_stats *d_stats, uint8_t *d_roles)
 {
@@ -605,8 +609,43 @@ int encode_payload_locked(EncSlot &E, const uint16_t *d_images, int n, int width
 		pa.spill_idx = (uint32_t *)E.e_spill.p;
 		pa.tflag = (uint32_t *)E.e_tflag.p; pa.tcount = pa.tflag + (size_t)n * NT; pa.tlist = pa.tcount + n;
 		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
-		HIP_TRY(launch_encode_pipe(pa, n, E.stream, &tune));
 		g_ctx.last_path = 1;
+		static const bool stamps = getenv("CCT_PIPE_STAMPS") != nullptr;
+		if (g_ctx.use_graph && !g_ctx.pipe_timing && !stamps) {
+			// replayed as a graph from the second call with the same arguments on: no dispatch gaps between the five nodes
+			std::vector<uint8_t> key(sizeof(PipeArgs) + 2 * sizeof(int));
+			memcpy(key.data(), &pa, sizeof(PipeArgs));
+			memcpy(key.data() + sizeof(PipeArgs), &n, sizeof(int));
+			memcpy(key.data() + sizeof(PipeArgs) + sizeof(int), &tune.tpw, sizeof(int));
+			EncSlot::PipeGraph *pg = nullptr;
+			for (auto &g : E.p_graphs) if (g.key == key) pg = &g;
+			if (!pg) {
+				if (E.p_graphs.size() >= 6) {  // forget the least recently used argument set
+					size_t old = 0;
+					for (size_t i = 1; i < E.p_graphs.size(); i++) if (E.p_graphs[i].last_use < E.p_graphs[old].last_use) old = i;
+					if (E.p_graphs[old].exec) (void)hipGraphExecDestroy(E.p_graphs[old].exec);
+					if (E.p_graphs[old].graph) (void)hipGraphDestroy(E.p_graphs[old].graph);
+					E.p_graphs.erase(E.p_graphs.begin() + (long)old);
+				}
+				E.p_graphs.emplace_back();
+				E.p_graphs.back().key = key;
+				E.p_graphs.back().last_use = ++E.p_clock;
+				HIP_TRY(launch_encode_pipe(pa, n, st, &tune));  // first sight: plain launches (also sets the kernel attributes)
+				return CCT_OK;
+			}
+			pg->last_use = ++E.p_clock;
+			if (!pg->exec) {
+				HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+				hipError_t le = launch_encode_pipe(pa, n, st, &tune);
+				hipError_t ce = hipStreamEndCapture(st, &pg->graph);
+				if (le != hipSuccess) return fail(CCT_E_DEVICE, "pipeline capture: %s", hipGetErrorString(le));
+				HIP_TRY(ce);
+				HIP_TRY(hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0));
+			}
+			HIP_TRY(hipGraphLaunch(pg->exec, st));
+			return CCT_OK;
+		}
+		HIP_TRY(launch_encode_pipe(pa, n, st, &tune));
 		return CCT_OK;
 	}
 	if (tb && tb->tiled) {
@@ -618,11 +657,11 @@ int encode_payload_locked(EncSlot &E, const uint16_t *d_images, int n, int width
 		ta.e = a;
 		ta.tile_org = tb->d_org; ta.tile_orient = tb->d_orient; ta.patterns = tb->d_pat;
 		ta.n_orient = tb->n_orient; ta.n_tiles = tb->n_tiles; ta.row_pitch = width;
-		HIP_TRY(launch_encode_tiles(ta, n, E.stream));
+		HIP_TRY(launch_encode_tiles(ta, n, st));
 		g_ctx.last_path = 2;
 		return CCT_OK;
 	}
-	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, E.stream));
+	HIP_TRY(launch_encode(a, n, bs, g_ctx.wg_threads, st));
 	g_ctx.last_path = 0;
 	return CCT_OK;
 }
@@ -799,6 +838,7 @@ int cct_shutdown(void)
 		if (E.stream_copy) (void)hipStreamSynchronize(E.stream_copy);
 		if (E.z_graph_exec) (void)hipGraphExecDestroy(E.z_graph_exec);
 		if (E.z_graph) (void)hipGraphDestroy(E.z_graph);
+		for (auto &g : E.p_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (int i = 0; i < E.n_bufs; i++) E.all_bufs[i]->release();
 		hipEvent_t evs[] = {E.ev_k0, E.ev_k1, E.ev_z0, E.ev_z1, E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -985,7 +1025,7 @@ int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int heigh
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
-	return encode_payload_locked(g_enc[0], d_images, n, width, height, block_size, flags, eof_byte, d_payload, payload_stride,
+	return encode_payload_locked(g_enc[0], g_ctx.stream, d_images, n, width, height, block_size, flags, eof_byte, d_payload, payload_stride,
 	                             d_payload_sizes, d_status, d_stats, d_roles);
 }
 
@@ -1039,8 +1079,10 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	if ((rc = E.e_status.ensure((size_t)n * 4))) return rc;
 	if ((rc = E.h_stage.ensure((size_t)n * stride))) return rc;
 	if ((rc = E.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
+	// (running this stage on a stream of the highest priority while the other slot is in its DEFLATE pass was tried: the
+	// kernels took as long as without, waves already resident are not displaced)
 	HIP_TRY(hipEventRecord(E.ev_k0, E.stream));
-	rc = encode_payload_locked(E, d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)E.e_payload.p, stride,
+	rc = encode_payload_locked(E, E.stream, d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)E.e_payload.p, stride,
 	                           (uint32_t *)E.e_sizes.p, (uint32_t *)E.e_status.p,
 	                           h_stats ? (cct_slice_stats *)E.e_stats.p : nullptr, nullptr);
 	if (rc) return rc;
