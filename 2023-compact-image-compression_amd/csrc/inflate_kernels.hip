@@ -39,7 +39,7 @@ constexpr int NT = 256;                       // lanes per stream
 constexpr int NWV = NT / 64;                  // waves per stream
 constexpr int INF_RING = 65536, INF_RMASK = INF_RING - 1, INF_FLUSH = 4096;
 constexpr int INF_IN = 16384, INF_CHUNK = 4096;
-constexpr int LL_BITS = 11;
+constexpr int LL_BITS = 12;
 constexpr int D_BITS = 10;
 constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24, K_TWO = 1u << 26;
 constexpr int SEG_BITS = 256;                 // compressed bits per lane and round
@@ -281,25 +281,6 @@ __device__ void build_tables(InfShared &S, int n)
 	__syncthreads();
 }
 
-// a code longer than the root table (or none at all): the interval test on lim[], see above; 0 = no such code
-template <bool DIST>
-__device__ __forceinline__ uint32_t long_code_entry(const InfShared &S, uint32_t lo)
-{
-	constexpr int FB = DIST ? D_BITS : LL_BITS;
-	const CanonLds &C = DIST ? S.d_canon : S.ll_canon;
-	const uint32_t *sent = DIST ? S.d_sent : S.ll_sent;
-	const uint32_t v = __brev(lo) >> 17;  // 15 bits, MSB = first stream bit
-	uint32_t lim[16], adj[16];
-#pragma unroll
-	for (int len = FB; len <= 15; len++) { lim[len] = C.lim[len]; adj[len] = C.adj[len]; }  // independent loads, one wait
-	int L = 0;
-	uint32_t a = 0;
-#pragma unroll
-	for (int len = 15; len > FB; len--) if (v < lim[len]) { L = len; a = adj[len]; }
-	if (v < lim[FB]) L = 0;  // a short code whose symbol is not valid (root entry 0)
-	return L ? sent[(v >> (15 - L)) + a] : 0u;
-}
-
 // per-lane bit reader over the staged input; bit positions are 32-bit offsets from the round's origin dword
 struct LaneBits { uint64_t buf; int cnt; uint32_t next; };  // next = dword index relative to br.src
 
@@ -339,6 +320,30 @@ __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, u
 	lane_init(S, lb, org_dword, start);
 	uint32_t p = start;  // bit position of the next symbol
 	nbytes = 0; nmatch = 0; flags = 0;
+	// interval limits of the codes longer than the root tables: wave-uniform, fetched once per walk
+	uint32_t ll_lim[16], ll_adj[16], d_lim[16], d_adj[16];
+#pragma unroll
+	for (int len = LL_BITS; len <= 15; len++) { ll_lim[len] = S.ll_canon.lim[len]; ll_adj[len] = S.ll_canon.adj[len]; }
+#pragma unroll
+	for (int len = D_BITS; len <= 15; len++) { d_lim[len] = S.d_canon.lim[len]; d_adj[len] = S.d_canon.adj[len]; }
+	auto long_ll = [&](uint32_t lo) -> uint32_t {  // a code longer than the root table (or none): the interval test, see CanonLds
+		const uint32_t v = __brev(lo) >> 17;
+		int L = 0;
+		uint32_t a = 0;
+#pragma unroll
+		for (int k = 15; k > LL_BITS; k--) if (v < ll_lim[k]) { L = k; a = ll_adj[k]; }
+		if (v < ll_lim[LL_BITS]) L = 0;  // a short code whose symbol is not valid (root entry 0)
+		return L ? S.ll_sent[(v >> (15 - L)) + a] : 0u;
+	};
+	auto long_d = [&](uint32_t lo) -> uint32_t {
+		const uint32_t v = __brev(lo) >> 17;
+		int L = 0;
+		uint32_t a = 0;
+#pragma unroll
+		for (int k = 15; k > D_BITS; k--) if (v < d_lim[k]) { L = k; a = d_adj[k]; }
+		if (v < d_lim[D_BITS]) L = 0;
+		return L ? S.d_sent[(v >> (15 - L)) + a] : 0u;
+	};
 	// invariant at the top of a step: more than 21 valid bits in lb.buf (a root lookup needs 11)
 	auto literal_step = [&](uint32_t e, bool live) {
 		const bool lit = live && (e & (3u << 24)) == K_LIT;
@@ -371,7 +376,7 @@ __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, u
 		uint32_t e = S.ll_tab[lo & ((1u << LL_BITS) - 1u)];
 		if (e == 0) {
 			if (steps) ++steps[1];
-			e = long_code_entry<false>(S, lo);
+			e = long_ll(lo);
 			if (e == 0) { flags = SEG_BAD; break; }
 		}
 		if (steps && (e & (3u << 24)) == K_LEN) ++steps[2];
@@ -385,7 +390,7 @@ __device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, u
 			const uint32_t dlo = (uint32_t)lb.buf;
 			uint32_t de = S.d_tab[dlo & ((1u << D_BITS) - 1u)];
 			if (de == 0) {
-				de = long_code_entry<true>(S, dlo);
+				de = long_d(dlo);
 				if (de == 0) { flags = SEG_BAD; break; }
 			}
 			const uint32_t dcb = de & 15u, dxb = (de >> 4) & 15u;
