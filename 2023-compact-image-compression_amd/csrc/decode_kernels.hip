@@ -203,9 +203,17 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	uint32_t *g_jord = a.ws_jord + (size_t)s * jcap;
 	uint8_t *g_jval = a.ws_jval + (size_t)s * jcap;
 
+#ifdef CCT_DEC_PROF  // tuning builds only: phase times of workgroup 0
+	long long tp[8]; int tpi = 0;
+#define DEC_STAMP() do { if (tpi < 8) tp[tpi++] = clock64(); } while (0)
+#else
+#define DEC_STAMP() do {} while (0)
+#endif
+	DEC_STAMP();
 	if (tid == 0) s_status = 0;
 	for (int b = tid; b < NB; b += T) role_wr((uint32_t)b, 0);
 	__syncthreads();
+	DEC_STAMP();
 
 	auto load_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt, int &nvalid) {
 		w = make_uint4(0, 0, 0, 0);
@@ -247,6 +255,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		}
 	}
 	__syncthreads();
+	DEC_STAMP();
 	if (npix_c < (uint32_t)N && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);  // ran out of tokens
 
 	// ------------------------------------------------------------------ resolve jumps -> role[]
@@ -285,6 +294,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		if (bad) atomicOr(&s_status, CCT_ST_STREAM);
 	}
 	__syncthreads();
+	DEC_STAMP();
 
 	// ------------------------------------------------------------------ slot table
 	{
@@ -308,6 +318,7 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		if (slot_c != (uint32_t)NB && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
 	}
 	__syncthreads();
+	DEC_STAMP();
 
 	// ------------------------------------------------------------------ pass B: pixels
 	if (!(s_status & CCT_ST_STREAM)) {
@@ -363,6 +374,14 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		}
 	}
 	__syncthreads();
+	DEC_STAMP();
+#ifdef CCT_DEC_PROF
+	if (s == 0 && tid == 0) {
+		printf("[decode prof] steps %u jumps %u:", nsteps, nj_c);
+		for (int i = 1; i < tpi; i++) printf(" %lld", tp[i] - tp[i - 1]);
+		printf("  (init+tables | pass A | resolve | slot table | pass B)\n");
+	}
+#endif
 	if (tid == 0) a.status[s] = s_status;
 }
 
