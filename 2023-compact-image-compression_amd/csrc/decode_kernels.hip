@@ -48,24 +48,72 @@ __device__ __forceinline__ uint32_t seg_byte(const uint4 &w, uint32_t nxt, int i
 	return (word >> ((i & 3) * 8)) & 0xFFu;
 }
 
-__device__ __forceinline__ SegStats seg_walk(const uint4 &w, uint32_t nxt, int nvalid, int entry)
+// ---- a 16-byte segment as bit masks (bit i = byte i) --------------------------------------------------------------
+// Walking the bytes one at a time costs ~30 instructions per byte, twice (both entry states), on a workgroup that is bound
+// by instruction issue (16 waves on a CU).  Everything the scans need is a property of three byte classes, so the classes
+// are extracted four bytes at a time (SWAR) and the token structure follows from mask arithmetic:
+//   F  bytes 1110xxxx (may open a two-byte full delta)     J  bytes 10xxxxxx (jump)     S  bytes 0xxxxxxx (short delta)
+// A byte is the second byte of a full delta iff the byte before it is an F byte that is not itself a second byte: inside a
+// run of F bytes the roles alternate.  That is the "escaped character" problem of JSON scanners; the carry of one
+// subtraction resolves all runs at once (Langdale & Lemire, simdjson: find_escaped).
+struct SegMasks { uint32_t F, J, S, V; };
+
+// the MSBs of the four bytes of m (nothing else set) as bits 0..3
+__device__ __forceinline__ uint32_t msb_nibble(uint32_t m) { return ((m >> 7) * 0x01020408u) >> 24; }
+
+__device__ __forceinline__ SegMasks seg_masks(const uint4 &w, int nvalid)
 {
-	SegStats st{0, 0, 0, 0};
-	int i = entry;
-	while (i < nvalid) {
-		const uint32_t c = seg_byte(w, nxt, i);
-		if ((c & 0xF0u) == 0xE0u) {
-			st.sdelta += tok_delta_full(c, seg_byte(w, nxt, i + 1));
-			st.npix++;
-			i += 2;
-		} else {
-			if ((c & 0xC0u) == 0x80u) st.njump++;
-			else { st.npix++; if (c < 0x80u) st.sdelta += tok_delta_short(c); }
-			i += 1;
-		}
+	const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+	SegMasks m{0, 0, 0, nvalid >= 16 ? 0xFFFFu : ((1u << max(nvalid, 0)) - 1u)};
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint32_t x = ws[k];
+		const uint32_t t = (x & 0xF0F0F0F0u) ^ 0xE0E0E0E0u;  // zero byte <=> high nibble 0xE
+		const uint32_t nz = (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+		m.F |= msb_nibble(nz ^ 0x80808080u) << (4 * k);
+		m.J |= msb_nibble(x & ~(x << 1) & 0x80808080u) << (4 * k);
+		m.S |= msb_nibble(~x & 0x80808080u) << (4 * k);
 	}
-	st.exit_state = (i > nvalid) ? 1u : 0u;
-	if (nvalid <= 0) st.exit_state = (uint32_t)entry;
+	m.F &= m.V; m.J &= m.V; m.S &= m.V;
+	return m;
+}
+
+// second bytes of full deltas (`second`) and the F bytes that really open one (`fulls`), for entry state e
+__device__ __forceinline__ void seg_structure(const SegMasks &m, uint32_t e, uint32_t &second, uint32_t &fulls)
+{
+	const uint32_t ODD = 0xAAAAAAAAu;
+	const uint32_t pe = m.F & ~e;
+	const uint32_t etc = (((pe << 1) | ODD) - pe) ^ ODD;
+	second = (etc ^ (m.F | e)) & m.V;
+	fulls = etc & m.F;
+}
+
+// what seg_walk() of the first version returned: tokens that START in the segment, for entry state e
+__device__ __forceinline__ SegStats seg_stats(const uint4 &w, uint32_t nxt, const SegMasks &m, int nvalid, uint32_t e)
+{
+	SegStats st{e, 0, 0, 0};
+	if (nvalid <= 0) return st;
+	uint32_t second, fulls;
+	seg_structure(m, e, second, fulls);
+	const uint32_t starts = m.V & ~second;
+	st.exit_state = (fulls >> (nvalid - 1)) & 1u;
+	st.njump = (uint32_t)__popc(starts & m.J);
+	st.npix = (uint32_t)__popc(starts & ~m.J);
+	// short deltas: sum of the selected bytes, minus 128 for every one above 64 (signed(x, 7))
+	const uint32_t sh = starts & m.S;
+	const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+	uint32_t sum = 0, big = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const uint32_t sel = (((sh >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;  // bits 0..3 -> the low bit of bytes 0..3
+		sum = __builtin_amdgcn_udot4(ws[k], sel, sum, false);
+		big += (uint32_t)__popc(((((ws[k] & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) & 0x80808080u) >> 7) & sel);
+	}
+	st.sdelta = (int32_t)sum - 128 * (int32_t)big;
+	for (uint32_t f = fulls; f; f &= f - 1) {  // full deltas are few
+		const int i = __ffs((int)f) - 1;
+		st.sdelta += tok_delta_full(seg_byte(w, nxt, i), seg_byte(w, nxt, i + 1));
+	}
 	return st;
 }
 
@@ -76,14 +124,20 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier
 	return map_apply(later, map_apply(earlier, 0)) | (map_apply(later, map_apply(earlier, 1)) << 1);
 }
 
+// cross-lane moves as DPP modifiers (VALU latency) instead of ds_bpermute (LDS latency); lanes without a source read OLD
+template <int CTRL, int OLD = 0, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_from(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(OLD, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-	const int lane = threadIdx.x & 63;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		uint32_t t = __shfl_up(v, d);
-		if (lane >= d) v += t;
-	}
+	v += dpp_from<0x111>(v);  // row_shr:1
+	v += dpp_from<0x112>(v);  // row_shr:2
+	v += dpp_from<0x114>(v);  // row_shr:4
+	v += dpp_from<0x118>(v);  // row_shr:8
+	v += dpp_from<0x142, 0, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+	v += dpp_from<0x143, 0, 0xC>(v);  // row_bcast:31 into rows 2 and 3
 	return v;
 }
 
@@ -103,17 +157,20 @@ __device__ __forceinline__ Parse parse_step(const uint4 &w, uint32_t nxt, int nv
                                            uint32_t &njump_carry)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	const SegStats s0 = seg_walk(w, nxt, nvalid, 0);
-	const SegStats s1 = seg_walk(w, nxt, nvalid, 1);
-	// inclusive scan of state maps inside the wave
+	const SegMasks sm = seg_masks(w, nvalid);
+	const SegStats s0 = seg_stats(w, nxt, sm, nvalid, 0);
+	const SegStats s1 = seg_stats(w, nxt, sm, nvalid, 1);
+	// inclusive scan of state maps inside the wave (lanes without a source compose with the identity map, 2)
 	uint32_t m = s0.exit_state | (s1.exit_state << 1);
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(m, d);
-		if (lane >= d) m = map_compose(m, t);
-	}
-	uint32_t excl = __shfl_up(m, 1);
-	if (lane == 0) excl = 2u;  // identity map
+	m = map_compose(m, dpp_from<0x111, 2>(m));
+	m = map_compose(m, dpp_from<0x112, 2>(m));
+	m = map_compose(m, dpp_from<0x114, 2>(m));
+	m = map_compose(m, dpp_from<0x118, 2>(m));
+	m = map_compose(m, dpp_from<0x142, 2, 0xA>(m));
+	m = map_compose(m, dpp_from<0x143, 2, 0xC>(m));
+	const uint32_t excl = dpp_from<0x138, 2>(m);  // wave_shr:1: the map of the lanes before this one
+	// scratch[0..15] holds the maps, scratch[16..47] the counts: a region is rewritten only after a barrier that every
+	// wave reaches after its reads of that region, so two barriers per step suffice
 	if (lane == 63) scratch[wave] = m;
 	__syncthreads();
 	uint32_t st_wave = st_carry, st_end = st_carry;
@@ -122,23 +179,22 @@ __device__ __forceinline__ Parse parse_step(const uint4 &w, uint32_t nxt, int nv
 		if (x < wave) st_wave = map_apply(wm, st_wave);
 		st_end = map_apply(wm, st_end);
 	}
-	__syncthreads();
 	Parse p;
 	p.entry = map_apply(excl, st_wave);
 	p.st = p.entry ? s1 : s0;
-	// scans of pixel count, delta sum and jump count
-	const uint32_t ip = wave_incl_scan_u32(p.st.npix);
+	// scans of pixel count | jump count << 16 (both <= 16 per lane, <= 16384 per step) and of the delta sum
+	const uint32_t ipj = wave_incl_scan_u32(p.st.npix | (p.st.njump << 16));
 	const uint32_t iv = wave_incl_scan_u32((uint32_t)p.st.sdelta);
-	const uint32_t ij = wave_incl_scan_u32(p.st.njump);
-	if (lane == 63) { scratch[wave] = ip; scratch[16 + wave] = iv; scratch[32 + wave] = ij; }
+	const uint32_t ip = ipj & 0xFFFFu, ij = ipj >> 16;
+	if (lane == 63) { scratch[16 + wave] = ipj; scratch[32 + wave] = iv; }
 	__syncthreads();
-	uint32_t bp = 0, bv = 0, bj = 0, tp = 0, tv = 0, tj = 0;
+	uint32_t bpj = 0, bv = 0, tpj = 0, tv = 0;
 	for (int x = 0; x < nw; x++) {
-		const uint32_t xp = scratch[x], xv = scratch[16 + x], xj = scratch[32 + x];
-		if (x < wave) { bp += xp; bv += xv; bj += xj; }
-		tp += xp; tv += xv; tj += xj;
+		const uint32_t xp = scratch[16 + x], xv = scratch[32 + x];
+		if (x < wave) { bpj += xp; bv += xv; }
+		tpj += xp; tv += xv;
 	}
-	__syncthreads();
+	const uint32_t bp = bpj & 0xFFFFu, bj = bpj >> 16, tp = tpj & 0xFFFFu, tj = tpj >> 16;
 	p.pix_base = npix_carry + bp + ip - p.st.npix;
 	p.val_base = val_carry + (int32_t)(bv + iv - (uint32_t)p.st.sdelta);
 	p.jump_base = njump_carry + bj + ij - p.st.njump;
@@ -241,16 +297,15 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 		const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
 		pcache[(size_t)nsteps * T + tid] = make_uint2(min(p.pix_base, 0x7FFFFFFFu) | (p.entry << 31), (uint32_t)p.val_base);
 		if (p.st.njump) {
-			int i = (int)p.entry;
-			uint32_t ord = p.pix_base, k = p.jump_base;
-			while (i < nvalid) {
-				const uint32_t c = seg_byte(w, nxt, i);
-				if ((c & 0xF0u) == 0xE0u) { ord++; i += 2; }
-				else {
-					if ((c & 0xC0u) == 0x80u) { if (ord < (uint32_t)N) jset(k, ord, c & 0x3Fu); k++; }
-					else ord++;
-					i += 1;
-				}
+			const SegMasks sm = seg_masks(w, nvalid);
+			uint32_t second, fulls;
+			seg_structure(sm, p.entry, second, fulls);
+			const uint32_t starts = sm.V & ~second, pix = starts & ~sm.J;
+			uint32_t k = p.jump_base;
+			for (uint32_t jm = starts & sm.J; jm; jm &= jm - 1, k++) {
+				const int i = __ffs((int)jm) - 1;
+				const uint32_t ord = p.pix_base + (uint32_t)__popc(pix & ((1u << i) - 1u));  // pixel tokens before the jump
+				if (ord < (uint32_t)N) jset(k, ord, seg_byte(w, nxt, i) & 0x3Fu);
 			}
 		}
 	}
@@ -259,17 +314,27 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	if (npix_c < (uint32_t)N && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);  // ran out of tokens
 
 	// ------------------------------------------------------------------ resolve jumps -> role[]
-	if (tid == 0) {
-		const uint32_t nj = nj_c;
+	if (tid < 64) {
+		// The replay is serial; wave 0 runs it with every loaded value made wave-uniform (v_readfirstlane), so that the state
+		// lives in SGPRs, the 64-bit window is shifted by scalar instructions and the loops branch without exec-mask juggling.
+		// Lane 0 does the stores.  The next jump is fetched while the current one is replayed.
+		auto uni = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+		const uint32_t nj = uni(nj_c);
 		uint32_t F = 0;          // frontier: next block in traversal order not yet emitted as a leader
 		uint64_t win = 0;        // bit t: block F+t already claimed as a partner
 		uint32_t slots_done = 0; // 16-pixel stream slots consumed before the frontier
 		bool bad = false;
-		for (uint32_t k = 0; k < nj && !bad; k++) {
-			uint32_t ord, j;
+		auto fetch = [&](uint32_t k, uint32_t &ord, uint32_t &j) {
+			ord = 0xFFFFFFFFu; j = 0;
 			if (k < DEC_JLIST_CAP) { ord = l_jord[k]; j = l_jval[k]; }
 			else if (k - DEC_JLIST_CAP < jcap) { ord = g_jord[k - DEC_JLIST_CAP]; j = g_jval[k - DEC_JLIST_CAP]; }
-			else { bad = true; break; }
+		};
+		uint32_t ord_n = 0, j_n = 0;
+		if (nj) fetch(0, ord_n, j_n);
+		for (uint32_t k = 0; k < nj && !bad; k++) {
+			if (k >= DEC_JLIST_CAP && k - DEC_JLIST_CAP >= jcap) { bad = true; break; }
+			const uint32_t ord = uni(ord_n), j = uni(j_n);
+			if (k + 1 < nj) fetch(k + 1, ord_n, j_n);
 			if (ord >= (uint32_t)N) break;  // tokens past the last pixel are never read
 			if (ord % BS != 0) { bad = true; break; }
 			const uint32_t sslot = ord / BS;
@@ -281,17 +346,16 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 				if (o >= remaining) { F += remaining; win >>= remaining; remaining = 0; }
 				else { F += o + 1; win = (o + 1 >= 64u) ? 0ull : (win >> (o + 1)); remaining -= o; }
 			}
-			while (win & 1ull) { F++; win >>= 1; }
+			{ const uint64_t free_ = ~win; const uint32_t t = free_ ? (uint32_t)__builtin_ctzll(free_) : 64u; F += t; win = t >= 64u ? 0ull : win >> t; }  // partners at the frontier
 			const uint32_t Lb = F, pb = F + j;
 			if (j == 0 || pb >= (uint32_t)NB || ((win >> j) & 1ull)) { bad = true; break; }
-			role_wr(Lb, j);
-			role_wr(pb, ROLE_PARTNER);
+			if (tid == 0) { role_wr(Lb, j); role_wr(pb, ROLE_PARTNER); }
 			win |= 1ull << j;
 			F = Lb + 1;
 			win >>= 1;
 			slots_done = sslot + 2;
 		}
-		if (bad) atomicOr(&s_status, CCT_ST_STREAM);
+		if (bad && tid == 0) atomicOr(&s_status, CCT_ST_STREAM);
 	}
 	__syncthreads();
 	DEC_STAMP();
@@ -330,45 +394,65 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 			const uint2 pc = pcache[(size_t)k * T + tid];
 			Parse p;
 			p.entry = pc.x >> 31; p.pix_base = pc.x & 0x7FFFFFFFu; p.val_base = (int32_t)pc.y;
-			int i = (int)p.entry;
+			// token structure of the segment as masks (see seg_masks): the loop below visits pixel tokens only
+			const SegMasks sm = seg_masks(w, nvalid);
+			uint32_t second, fulls;
+			seg_structure(sm, p.entry, second, fulls);
+			uint32_t starts = sm.V & ~second, pix = starts & ~sm.J;
 			uint32_t ord = p.pix_base;
 			int32_t val = p.val_base;
 			uint32_t flags = 0;
-			bool after_jump = false;
-			while (i < nvalid && ord < (uint32_t)N) {
+			// the reference stops reading after pixel N - 1: tokens behind it do not exist for the decoder
+			const uint32_t room = ord < (uint32_t)N ? (uint32_t)N - ord : 0u;
+			if ((uint32_t)__popc(pix) > room) {
+				uint32_t keep = 0;
+				if (room) {
+					uint32_t pm = pix;
+					for (uint32_t r = 1; r < room; r++) pm &= pm - 1;
+					keep = (2u << (__ffs((int)pm) - 1)) - 1u;  // up to and including the last wanted pixel token
+				}
+				starts &= keep; pix &= keep; fulls &= keep;
+			}
+			const uint32_t jm = starts & sm.J;
+			if (jm & (jm << 1)) flags |= CCT_ST_STREAM;  // two jump bytes in a row
+			if (nvalid > 0 && ((fulls >> (nvalid - 1)) & 1u) && seg_start + (uint32_t)nvalid >= Lr) flags |= CCT_ST_STREAM;  // second byte missing
+			// a lane's pixels fall into at most two stream slots: slot entry, partner and tile data are fetched once per slot
+			uint32_t cur_sl = 0xFFFFFFFFu, kind = 0, blk0 = 0, blk1 = 0;
+			uint32_t org0 = 0, org1 = 0, pat0 = 0, pat1 = 0;
+			for (uint32_t pm = pix; pm; pm &= pm - 1) {
+				const int i = __ffs((int)pm) - 1;
 				const uint32_t c = seg_byte(w, nxt, i);
-				bool is_pixel = true;
-				if ((c & 0xF0u) == 0xE0u) {
-					if (seg_start + (uint32_t)i + 1u >= Lr) flags |= CCT_ST_STREAM;  // second byte missing
-					val += tok_delta_full(c, seg_byte(w, nxt, i + 1));
-					i += 2;
-				} else if (c < 0x80u) {
-					val += tok_delta_short(c);
-					i += 1;
-				} else if ((c & 0xC0u) == 0x80u) {
-					if (after_jump) flags |= CCT_ST_STREAM;  // two jump bytes in a row
-					is_pixel = false;
-					after_jump = true;
-					i += 1;
-				} else {
-					i += 1;  // reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats
-				}
-				if (is_pixel) {
-					after_jump = false;
-					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
-					const uint32_t sl = ord / BS, t = ord % BS;
+				if ((sm.S >> i) & 1u) val += tok_delta_short(c);
+				else if ((fulls >> i) & 1u) val += tok_delta_full(c, seg_byte(w, nxt, i + 1));
+				// (reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats)
+				if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
+				const uint32_t sl = ord / BS, t = ord % BS;
+				if (sl != cur_sl) {
+					cur_sl = sl;
 					const uint32_t ent = slot_rd(sl);
-					const uint32_t b = ent & 0x3FFFFFFFu, kind = ent >> 30;
-					uint32_t pos;
-					if (kind == 0) pos = b * BS + t;
-					else {
-						const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
-						const uint32_t blk = (mm & 1u) ? b + role_rd(b) : b;
-						pos = blk * BS + (mm >> 1);
+					blk0 = ent & 0x3FFFFFFFu; kind = ent >> 30;
+					blk1 = kind ? blk0 + role_rd(blk0) : blk0;
+					if (TILED) {
+						const uint32_t t0 = (blk0 * BS) >> 12, t1 = (blk1 * BS) >> 12;
+						org0 = l_torg[t0]; pat0 = (uint32_t)l_tori[t0] * 4096u;
+						org1 = l_torg[t1]; pat1 = (uint32_t)l_tori[t1] * 4096u;
 					}
-					out[raster_of(pos)] = (uint16_t)val;
-					ord++;
 				}
+				uint32_t pos, odd = 0;
+				if (kind == 0) pos = blk0 * BS + t;
+				else {
+					const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
+					odd = mm & 1u;
+					pos = (odd ? blk1 : blk0) * BS + (mm >> 1);
+				}
+				uint32_t ras;
+				if (TILED) {
+					const uint32_t pv = l_pat[(odd ? pat1 : pat0) + (pos & 4095u)];  // dy*128 + ((dx>>3 ^ dy&7) << 4) + (dx&7)*2
+					const uint32_t dy = pv >> 7, dx = ((((pv >> 4) & 7u) ^ (dy & 7u)) << 3) | ((pv & 15u) >> 1);
+					ras = (odd ? org1 : org0) + dy * (uint32_t)a.width + dx;
+				} else ras = raster_of(pos);
+				out[ras] = (uint16_t)val;
+				ord++;
 			}
 			if (flags) atomicOr(&s_status, flags);
 		}
