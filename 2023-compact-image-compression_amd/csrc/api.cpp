@@ -784,6 +784,10 @@ struct Rccl {
 	void *comm = nullptr;
 	int rank = -1, world = 0;
 	DevBuf d_send, d_recv;
+	// the collective has a stream and a mutex of its own: on the main stream the gather of a few hundred sizes would queue
+	// behind the ten milliseconds of kernels of the encode batch in slot 0, once per step
+	hipStream_t stream = nullptr;
+	std::mutex mu;
 } g_rccl;
 
 int rccl_load()
@@ -845,8 +849,12 @@ int cct_shutdown(void)
 		if (E.stream_copy) (void)hipStreamDestroy(E.stream_copy);
 		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
 	}
-	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; g_rccl.rank = -1; g_rccl.world = 0; }
-	g_rccl.d_send.release(); g_rccl.d_recv.release();
+	{
+		std::lock_guard<std::mutex> lkc(g_rccl.mu);
+		if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; g_rccl.rank = -1; g_rccl.world = 0; }
+		g_rccl.d_send.release(); g_rccl.d_recv.release();
+		if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
+	}
 	for (auto &kv : g_ctx.luts) {
 		ShapeTables &t = kv.second;
 		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
@@ -1560,6 +1568,8 @@ int cct_comm_init(const void *id128, int rank, int world)
 	if (g_rccl.comm) return fail(CCT_E_ARG, "a communicator already exists");
 	cct_unique_id_t id;
 	memcpy(&id, id128, CCT_COMM_ID_BYTES);
+	std::lock_guard<std::mutex> lkc(g_rccl.mu);
+	if (!g_rccl.stream) HIP_TRY(hipStreamCreateWithFlags(&g_rccl.stream, hipStreamNonBlocking));
 	const int r = g_rccl.CommInitRank(&g_rccl.comm, world, id, rank);
 	if (r) { g_rccl.comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
 	g_rccl.rank = rank; g_rccl.world = world;
@@ -1568,7 +1578,7 @@ int cct_comm_init(const void *id128, int rank, int world)
 
 int cct_comm_info(int *rank, int *world)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::mutex> lk(g_rccl.mu);
 	if (rank) *rank = g_rccl.comm ? g_rccl.rank : -1;
 	if (world) *world = g_rccl.comm ? g_rccl.world : 0;
 	return CCT_OK;
@@ -1577,30 +1587,33 @@ int cct_comm_info(int *rank, int *world)
 int cct_allgather_u32(const uint32_t *h_local, int n_local, int max_local, uint32_t *h_all)
 {
 	if (n_local < 0 || max_local < n_local || (n_local && !h_local) || !h_all) return fail(CCT_E_ARG, "bad all-gather arguments");
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::mutex> lk(g_rccl.mu);
 	if (!g_rccl.comm) {
 		for (int i = 0; i < max_local; i++) h_all[i] = i < n_local ? h_local[i] : 0u;
 		return CCT_OK;
 	}
-	int rc = ensure_ctx();
-	if (rc) return rc;
+	if (g_ctx.pid != getpid()) return fail(CCT_E_DEVICE, "this process was forked after the communicator was created");
+	HIP_TRY(hipSetDevice(g_ctx.device));
+	int rc;
 	const size_t bytes = (size_t)std::max(max_local, 1) * 4;
 	if ((rc = g_rccl.d_send.ensure(bytes)) || (rc = g_rccl.d_recv.ensure(bytes * g_rccl.world))) return rc;
-	HIP_TRY(hipMemsetAsync(g_rccl.d_send.p, 0, bytes, g_ctx.stream));
-	if (n_local) HIP_TRY(hipMemcpyAsync(g_rccl.d_send.p, h_local, (size_t)n_local * 4, hipMemcpyHostToDevice, g_ctx.stream));
-	const int r = g_rccl.AllGather(g_rccl.d_send.p, g_rccl.d_recv.p, (size_t)max_local, 3 /* ncclUint32 */, g_rccl.comm, g_ctx.stream);
+	hipStream_t st = g_rccl.stream;
+	HIP_TRY(hipMemsetAsync(g_rccl.d_send.p, 0, bytes, st));
+	if (n_local) HIP_TRY(hipMemcpyAsync(g_rccl.d_send.p, h_local, (size_t)n_local * 4, hipMemcpyHostToDevice, st));
+	const int r = g_rccl.AllGather(g_rccl.d_send.p, g_rccl.d_recv.p, (size_t)max_local, 3 /* ncclUint32 */, g_rccl.comm, st);
 	if (r) return rccl_fail("ncclAllGather", r);
-	HIP_TRY(hipMemcpyAsync(h_all, g_rccl.d_recv.p, (size_t)max_local * 4 * g_rccl.world, hipMemcpyDeviceToHost, g_ctx.stream));
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+	HIP_TRY(hipMemcpyAsync(h_all, g_rccl.d_recv.p, (size_t)max_local * 4 * g_rccl.world, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
 	return CCT_OK;
 }
 
 int cct_comm_destroy(void)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
+	std::lock_guard<std::mutex> lk(g_rccl.mu);
 	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
 	g_rccl.rank = -1; g_rccl.world = 0;
 	g_rccl.d_send.release(); g_rccl.d_recv.release();
+	if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
 	return CCT_OK;
 }
 
