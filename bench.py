@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--slices", type=int, default=None, help="slices per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
+    ap.add_argument("--encode-slots", type=int, default=1, choices=(1, 2),
+                    help="encode batches on the device at a time (library option encode_slots; 2 is a few percent faster end to "
+                         "end, but then every kernel's duration includes another batch's DEFLATE pass next to it)")
     args = ap.parse_args()
     edge, n = WORKLOADS[args.config]
     if args.slices:
@@ -195,6 +198,7 @@ def main():
     if os.environ.get("CCT_HOST_THREADS"):
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
+    _ffi.check(L.cct_set_option(b"encode_slots", args.encode_slots))
     for env, key in (("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
                      ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path"),
                      ("CCT_ENCODE_SLOTS", b"encode_slots")):
@@ -314,6 +318,20 @@ def main():
         verified &= oracle.encode(batches[last][j]) == h_arch[kset][int(h_offs[kset][j]):int(h_offs[kset][j + 1])].tobytes()
     all_sizes = state["sizes"]
 
+    # ---- the same loop with the other encode-slot setting, outside the timed region (20 steps): what the setting is worth
+    other = None
+    if not decode_only and overlap and not multi:
+        other_slots = 2 if args.encode_slots == 1 else 1
+        _ffi.check(L.cct_set_option(b"encode_slots", other_slots))
+        ko = min(20, args.steps)
+        run_steps(0, args.warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, ko, False)
+        barrier()
+        other = {"encode_slots": other_slots, "MPixels_s": round(npx * ko / (time.perf_counter() - t0) / 1e6, 1), "steps": ko}
+        _ffi.check(L.cct_set_option(b"encode_slots", args.encode_slots))
+
     # ---- the transform+pack stage with nothing else on the device (outside the timed region): in the timed region two encode
     # batches and a decode share the chip, so the stage's events there measure its kernels next to another batch's DEFLATE
     alone_ms = None
@@ -369,8 +387,8 @@ def main():
                      "avg_kernel_ms": round(enc_kernel_ms, 4),
                      "alone": {"avg_ms": round(alone_ms, 4), "frac": round(2.0 * npx / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "the same launches with nothing else on the device (median of 10, after the timed region); "
-                                       "avg_ms / frac above are measured live, while another batch's DEFLATE pass and a decode "
-                                       "share the chip"} if alone_ms else None})
+                                       "avg_ms / frac above are measured live, while a decode (and, with --encode-slots 2, another "
+                                       "batch's DEFLATE pass) shares the chip"} if alone_ms else None})
         deflate_ms, inflate_ms, dec_ms = acc["deflate"] / ne, acc["inflate"] / nd, acc["dec_kernel"] / nd
         others = {
             "deflate": roof("device DEFLATE pass (sort, match, lazy parse, trees, emit: ~25 kernels as one graph)",
@@ -393,7 +411,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of {n} synthetic {W}x{H} uint16 CT slices per GPU, "
                                    f"{what}, {N_ROT} rotating device-resident batches",
                        "slices_per_gpu": n, "width": W, "height": H, "block_size": bs,
-                       "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)"},
+                       "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)",
+                       "encode_slots": args.encode_slots},
             "roofline": main_roof,
             "rooflines": others if decode_only else dict(others, transform_pack=pack),
             "stages": {
@@ -407,6 +426,7 @@ def main():
                 "deflate": "device (deflate_kernels.hip, byte-identical to zlib 1.2.11 level 9)" if dev_deflate.value
                 else "host libz thread team", "inflate": "device (inflate_kernels.hip, speculative lane-parallel decode)" if dev_inflate.value
                 else "host libz thread team",
+                "other_encode_slot_setting": other,
                 "note": "enc/dec = wall time of the C calls; with overlap two encode calls are in flight, so enc includes "
                         "the wait for the device lock",
                 "host_threads": zthreads, "host_cpus": os.cpu_count() or 1,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything profiles/ holds for a round, in one call (about six minutes).
 #   default bench (with the CPU baseline) -> the same command under rocprofv3 --kernel-trace --stats ->
-#   one encode slot, no overlap, configs 4 and 5 -> HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) and SQ
+#   two encode slots, no overlap, configs 4 and 5 -> HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) and SQ
 #   counters of the transform+pack kernels.  Copy what is kept from gpurun_out/round_end/ into profiles/ (tools/collect_profiles.py).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/round_end
@@ -13,12 +13,12 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 rm -rf $O/prof
 echo "traced bench done"
-CCT_ENCODE_SLOTS=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_one_slot.json 2> $O/bench_one_slot.err
-CCT_ENCODE_SLOTS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python bench.py --no-cpu-baseline --steps 20 > $O/bench_one_slot_under_rocprof.json 2> $O/bench_one_slot_under_rocprof.err
-find $O/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_one_slot_kernel_stats.csv
+timeout -k 10 300 python bench.py --no-cpu-baseline --encode-slots 2 > $O/bench_two_slots.json 2> $O/bench_two_slots.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python bench.py --no-cpu-baseline --encode-slots 2 --steps 20 > $O/bench_two_slots_under_rocprof.json 2> $O/bench_two_slots_under_rocprof.err
+find $O/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_two_slots_kernel_stats.csv
 rm -rf $O/prof1
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-overlap > $O/bench_no_overlap.json 2> $O/bench_no_overlap.err
-echo "one slot / no overlap done"
+echo "two slots / no overlap done"
 timeout -k 10 600 python bench.py --config 4 --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err
 timeout -k 10 300 python bench.py --config 5 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
 echo "configs 4, 5 done"
@@ -34,6 +34,6 @@ timeout -k 10 200 python tools/prof_encode.py --paths 1,2 --reps 30 > $O/prof_en
 echo "pmc done"
 python -c "
 import json
-for f in ('bench','bench_one_slot','bench_no_overlap','bench_config4','bench_config5'):
+for f in ('bench','bench_two_slots','bench_no_overlap','bench_config4','bench_config5'):
     d=json.load(open('$O/'+f+'.json')); print(f, d['value'], d['ms_per_step'], d['roofline']['avg_ms'], d['roofline']['frac'])
 "
