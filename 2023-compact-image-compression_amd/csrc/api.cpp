@@ -113,7 +113,7 @@ struct EncSlot {
 	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	DevBuf h_stage;  // pinned host staging (payloads)
 	// device DEFLATE workspaces
-	DevBuf z_keys_in, z_keys_out, z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
+	DevBuf z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
 	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
 	float t_dev_deflate_ms = 0;
 	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
@@ -123,7 +123,7 @@ struct EncSlot {
 	EncSlot()
 	{
 		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
-		               &e_spill, &e_tflag, &h_stage, &z_keys_in, &z_keys_out, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
+		               &e_spill, &e_tflag, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
 		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
 		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1]};
 		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
@@ -676,10 +676,8 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	if (EB >= ((size_t)1 << 32)) return fail(CCT_E_ARG, "deflate batch of %zu bytes exceeds the 4 GiB sort limit; split the batch", EB);
 	const int max_blocks = (int)(in_stride / 16383 + 2);
 	int rc;
-	if ((rc = E.z_keys_in.ensure(EB * 2))) return rc;
-	if ((rc = E.z_keys_out.ensure(EB * 2))) return rc;
-	if ((rc = E.z_vals_in.ensure(EB * 4))) return rc;
-	if ((rc = E.z_vals_out.ensure(EB * 4))) return rc;
+	if ((rc = E.z_vals_in.ensure(EB * 8))) return rc;   // records between the two sort passes, then run_ends + run_len
+	if ((rc = E.z_vals_out.ensure(EB * 8))) return rc;  // sorted records
 	if ((rc = E.z_mr.ensure(EB * 8))) return rc;
 	if ((rc = E.z_rec.ensure(EB * 4))) return rc;
 	if ((rc = E.z_sym.ensure(EB * 4))) return rc;
@@ -699,14 +697,13 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	if ((rc = E.z_sorttmp.ensure(tmp + 256))) return rc;
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
-	a.keys_in = (uint16_t *)E.z_keys_in.p; a.keys_out = (uint16_t *)E.z_keys_out.p;
-	a.vals_in = (uint32_t *)E.z_vals_in.p; a.vals_out = (uint32_t *)E.z_vals_out.p;
+	a.rec_in = (uint64_t *)E.z_vals_in.p; a.rec_out = (uint64_t *)E.z_vals_out.p;
 	uint32_t *small = (uint32_t *)E.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
 	a.mr = E.z_mr.p; a.heavy_list = (uint32_t *)E.z_rec.p; a.sym = (uint32_t *)E.z_sym.p;
-	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the unsorted (hash, position) input is dead after the sort
-	a.run_len = (uint16_t *)E.z_keys_in.p;
+	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the half-sorted records are dead after the sort: 4 EB for the run list ...
+	a.run_len = (uint16_t *)((uint8_t *)E.z_vals_in.p + EB * 4);  // ... and 2 EB for the run lengths
 	a.rec32 = (uint32_t *)E.z_exitp.p; a.exit_pos = (uint32_t *)E.z_exitc.p; a.exit_cnt = (uint32_t *)E.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
 	a.blk_entry = (uint32_t *)E.z_bentry.p; a.blk_symbase = (uint32_t *)E.z_bsym.p;
 	a.blk_end = (uint32_t *)E.z_bend.p;

@@ -133,7 +133,7 @@ struct BlockTables {
 };
 struct DeflateArgs {
 	const uint8_t *in; size_t in_stride; const uint32_t *in_sizes;  // token payloads (device)
-	uint16_t *keys_in, *keys_out; uint32_t *vals_in, *vals_out;      // n * in_stride each
+	uint64_t *rec_in, *rec_out;                                      // n * in_stride each: position | hash << 32, between / after the sort passes
 	uint32_t *seg_begin, *seg_end;                                   // n
 	void *mr;                                                        // n * in_stride * 8 bytes
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each

@@ -86,10 +86,11 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
 	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
-	const uint16_t *keys_src = a.keys_in + base;
-	const uint32_t *vals_src = a.vals_in + base;
-	uint16_t *keys_dst = (FIRST ? a.keys_in : a.keys_out) + base;
-	uint32_t *vals_dst = (FIRST ? a.vals_in : a.vals_out) + base;
+	// one 8-byte record per string: position | hash << 32.  The scatter below is bound by store transactions (every lane
+	// of a store instruction hits another output stream), so key and value travel in one store, and the match kernels
+	// get both with one scattered load
+	const uint64_t *rec_src = a.rec_in + base;
+	uint64_t *rec_dst = (FIRST ? a.rec_in : a.rec_out) + base;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 	if (tid < 256) offs[tid] = 0;
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		h = 0; p = idx;
 		if (idx < npos) {
 			if (FIRST) h = (((uint32_t)in[idx] << 10) ^ ((uint32_t)in[idx + 1] << 5) ^ in[idx + 2]) & 0x7FFFu;
-			else { h = keys_src[idx]; p = vals_src[idx]; }
+			else { const uint64_t r = rec_src[idx]; h = (uint32_t)(r >> 32); p = (uint32_t)r; }
 		}
 	};
 	uint32_t hn[E], pn[E];
@@ -172,8 +173,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			if (idx0 + e * 64 < npos) {
 				const uint32_t d = FIRST ? (h[e] & 255u) : (h[e] >> 8);
 				const uint32_t dst = wcnt[wave][d] + rk[e];
-				keys_dst[dst] = (uint16_t)h[e];
-				vals_dst[dst] = p[e];
+				rec_dst[dst] = (uint64_t)p[e] | ((uint64_t)h[e] << 32);
 			}
 		}
 	}
@@ -306,8 +306,7 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
 	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
-	const uint16_t *keys = a.keys_out + base;
-	const uint32_t *vals = a.vals_out + base;
+	const uint64_t *recs = a.rec_out + base;  // sorted (hash, position) records: position | hash << 32
 	MatchRec *mr = reinterpret_cast<MatchRec *>(a.mr) + base;
 	uint32_t *heavy = a.heavy_list + base;
 	const uint16_t *rl = a.run_len + base;
@@ -317,8 +316,9 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 		const uint32_t i = i0 + threadIdx.x;
 		int kind = 0;  // 0: record written, 1: queue for the cooperative heavy pass, 2: queue for the run pass
 		if (i < npos) {
-			const uint32_t p = vals[i];
-			const uint32_t h = keys[i];
+			const uint64_t ri = recs[i];
+			const uint32_t p = (uint32_t)ri;
+			const uint32_t h = (uint32_t)(ri >> 32);
 			const uint32_t lookahead = L - p;
 			const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
 			const uint32_t nil_q = nil_candidate(p, lookahead);
@@ -341,9 +341,11 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 				if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
 				else kind = 2;
 			} else {
-				for (int64_t j = (int64_t)i - 1; j >= 0 && keys[j] == h; j--) {
+				for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
+					const uint64_t rj = recs[j];
+					if ((uint32_t)(rj >> 32) != h) break;
 					if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
-					const uint32_t q = vals[j];
+					const uint32_t q = (uint32_t)rj;
 					const uint32_t dist = p - q;
 					if (q == 0 || q == nil_q) break;                         // NIL ends the chain
 					if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
@@ -389,10 +391,10 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 
 // Wave-cooperative longest_match for one position whose chain is long: 64 candidates per step.
 // Returns the packed MatchRec (lo = len4096 | len1024 << 16, hi = dist4096 | dist1024 << 16), wave-uniform.
-__device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint16_t *keys, const uint32_t *vals, uint32_t L,
+__device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint64_t *recs, uint32_t L,
                                                    uint32_t i, uint32_t p, int lane, uint32_t &lo, uint32_t &hi)
 {
-	const uint32_t h = keys[i];
+	const uint32_t h = (uint32_t)(recs[i] >> 32);
 	const uint32_t lookahead = L - p;
 	const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
 	const uint32_t nil_q = nil_candidate(p, lookahead);
@@ -403,8 +405,9 @@ __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint
 	uint32_t q1024 = 0;
 	for (int r = 0; r < 64; r++) {  // 64 x 64 = max_chain_length 4096 candidates
 		const int64_t j = (int64_t)i - 1 - (int64_t)(r * 64 + lane);
-		const bool in_chain = j >= 0 && keys[j] == h;
-		const uint32_t q = in_chain ? vals[j] : 0u;
+		const uint64_t rj = j >= 0 ? recs[j] : ~0ull;
+		const bool in_chain = j >= 0 && (uint32_t)(rj >> 32) == h;
+		const uint32_t q = in_chain ? (uint32_t)rj : 0u;
 		const uint32_t dist = p - q;
 		const bool term = !in_chain || q == 0 || q == nil_q ||
 		                  ((r == 0 && lane == 0) ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST);
@@ -441,17 +444,16 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
-	const uint16_t *keys = a.keys_out + base;
-	const uint32_t *vals = a.vals_out + base;
+	const uint64_t *recs = a.rec_out + base;  // sorted (hash, position) records: position | hash << 32
 	uint2 *mr = reinterpret_cast<uint2 *>(a.mr) + base;
 	const uint32_t *heavy = a.heavy_list + base;
 	const uint32_t nheavy = a.heavy_count[s];
 	const int lane = threadIdx.x & 63;
 	for (uint32_t e = part * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += nparts * (blockDim.x >> 6)) {
 		const uint32_t i = heavy[e];
-		const uint32_t p = vals[i];
+		const uint32_t p = (uint32_t)recs[i];
 		uint32_t lo, hi;
-		coop_longest_match(in, keys, vals, L, i, p, lane, lo, hi);
+		coop_longest_match(in, recs, L, i, p, lane, lo, hi);
 		if (lane == 0) mr[p] = make_uint2(lo, hi);
 	}
 }
@@ -548,8 +550,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
-	const uint16_t *keys = a.keys_out + base;
-	const uint32_t *vals = a.vals_out + base;
+	const uint64_t *recs = a.rec_out + base;  // sorted (hash, position) records: position | hash << 32
 	uint2 *mr = reinterpret_cast<uint2 *>(a.mr) + base;
 	const uint32_t *deep = a.heavy_list + base + a.in_stride - 1;  // grows downwards from the end
 	const uint32_t ndeep = a.deep_count[s];
@@ -558,8 +559,9 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 	const uint32_t nre = a.run_end_count[s];
 	for (uint32_t e = part * blockDim.x + threadIdx.x; e < ndeep; e += nparts * blockDim.x) {
 		const uint32_t i = *(deep - e);
-		const uint32_t p = vals[i];
-		const uint32_t h = keys[i];
+		const uint64_t ri = recs[i];
+		const uint32_t p = (uint32_t)ri;
+		const uint32_t h = (uint32_t)(ri >> 32);
 		const uint32_t lookahead = L - p;
 		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
 		const uint8_t b = in[p];
@@ -568,8 +570,9 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 		uint32_t best4 = has_prev ? r : 0u, q4 = p - 1, best1 = best4, q1 = p - 1;
 		bool scan = true;
 		if (!has_prev) {  // chain head rules of deflate_slow / longest_match
-			const bool have_head = i >= 1 && keys[i - 1] == h;
-			const uint32_t hq = have_head ? vals[i - 1] : 0u;
+			const uint64_t rh = i >= 1 ? recs[i - 1] : ~0ull;
+			const bool have_head = i >= 1 && (uint32_t)(rh >> 32) == h;
+			const uint32_t hq = have_head ? (uint32_t)rh : 0u;
 			if (!have_head || hq == 0 || hq == nil_candidate(p, lookahead) || p - hq > (uint32_t)MAX_DIST) scan = false;
 			else if (p - hq == (uint32_t)MAX_DIST) {  // only the head itself may sit at distance MAX_DIST
 				uint32_t len = 0;
@@ -583,8 +586,8 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 			const uint8_t c = ext_ok ? in[p + r] : 0;
 			const uint32_t qw = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1 : 1u;  // dist < MAX_DIST, q != NIL
 			uint32_t qmin4 = qw, qmin1 = qw;
-			if (i >= 4096 && keys[i - 4096] == h) qmin4 = max(qmin4, vals[i - 4096]);
-			if (i >= 1024 && keys[i - 1024] == h) qmin1 = max(qmin1, vals[i - 1024]);
+			if (i >= 4096) { const uint64_t r4 = recs[i - 4096]; if ((uint32_t)(r4 >> 32) == h) qmin4 = max(qmin4, (uint32_t)r4); }
+			if (i >= 1024) { const uint64_t r1 = recs[i - 1024]; if ((uint32_t)(r1 >> 32) == h) qmin1 = max(qmin1, (uint32_t)r1); }
 			uint32_t lo = 0, hi = nre;  // last run end <= p (none lies strictly inside p's own run)
 			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
@@ -1584,10 +1587,10 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	(void)sort_temp; (void)sort_temp_bytes;
-	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> (keys_in, vals_in) by hash & 255
-	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> (keys_out, vals_out) by hash >> 8
+	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> rec_in by hash & 255
+	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> rec_out by hash >> 8
 	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);
-	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over keys_in, dead after the sort
+	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over the upper part of rec_in, dead after the sort
 	const int gm = (int)std::min<size_t>(2048, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
 	hipLaunchKernelGGL(dfl_match_kernel, dim3(gm, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);

@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--slices", type=int, default=None, help="slices per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
+    ap.add_argument("--no-slot-comparison", action="store_true",
+                    help="skip the short run with the other --encode-slots setting after the timed region (use under a tracer)")
     ap.add_argument("--encode-slots", type=int, default=1, choices=(1, 2),
                     help="encode batches on the device at a time (library option encode_slots; 2 is a few percent faster end to "
                          "end, but then every kernel's duration includes another batch's DEFLATE pass next to it)")
@@ -320,7 +322,7 @@ def main():
 
     # ---- the same loop with the other encode-slot setting, outside the timed region (20 steps): what the setting is worth
     other = None
-    if not decode_only and overlap and not multi:
+    if not decode_only and overlap and not multi and not args.no_slot_comparison:
         other_slots = 2 if args.encode_slots == 1 else 1
         _ffi.check(L.cct_set_option(b"encode_slots", other_slots))
         ko = min(20, args.steps)

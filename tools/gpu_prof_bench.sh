@@ -2,7 +2,7 @@
 # run on the GPU box: per-kernel times of the bench loop (encode and decode overlapped, as measured) from rocprofv3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_b
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b -- python bench.py --steps 20 --warmup 3 "$@" > gpurun_out/bench_traced.json 2> gpurun_out/bench_traced.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b -- python bench.py --steps 20 --warmup 3 --no-slot-comparison --no-cpu-baseline "$@" > gpurun_out/bench_traced.json 2> gpurun_out/bench_traced.err
 f=$(find gpurun_out/prof_b -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/bench_kernel_stats.csv
 python3 - <<'PY'

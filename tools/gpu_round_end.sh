@@ -9,12 +9,12 @@ rm -rf $O && mkdir -p $O
 set -e
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
 echo "default bench done"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --no-cpu-baseline --no-slot-comparison > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 rm -rf $O/prof
 echo "traced bench done"
 timeout -k 10 300 python bench.py --no-cpu-baseline --encode-slots 2 > $O/bench_two_slots.json 2> $O/bench_two_slots.err
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python bench.py --no-cpu-baseline --encode-slots 2 --steps 20 > $O/bench_two_slots_under_rocprof.json 2> $O/bench_two_slots_under_rocprof.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python bench.py --no-cpu-baseline --no-slot-comparison --encode-slots 2 --steps 20 > $O/bench_two_slots_under_rocprof.json 2> $O/bench_two_slots_under_rocprof.err
 find $O/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_two_slots_kernel_stats.csv
 rm -rf $O/prof1
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-overlap > $O/bench_no_overlap.json 2> $O/bench_no_overlap.err
