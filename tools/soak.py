@@ -14,18 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "2023-compact-image-compression_amd")]
 import cct_hip  # noqa: E402
 from cct_hip import _ffi  # noqa: E402
-from bench import make_batches, W, H  # noqa: E402
+from bench import make_batches  # noqa: E402
+W = H = 512
 import xxhash  # noqa: E402
 
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    n = 256
+    batches = make_batches(0, n)  # forks a process pool: before the first GPU call
     L = _ffi.lib()
     _ffi.check(L.cct_init(0))
     cfg = cct_hip.default_config()
     flags, bs, eof, magic, ch, bpc = cct_hip.codec_params(cfg, np.uint16)
-    n = 256
-    batches = make_batches(0, n)
     d_imgs = [cct_hip.DeviceBuffer.from_numpy(b) for b in batches]
     NSET = 3
     cap = n * L.cct_file_bound(W, H, bs)
