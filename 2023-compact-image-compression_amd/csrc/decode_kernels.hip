@@ -238,20 +238,29 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	auto slot_rd = [&](uint32_t i) -> uint32_t { return TAB_LDS ? l_slot[i] : g_slot[i]; };
 	auto slot_wr = [&](uint32_t i, uint32_t v) { if (TAB_LDS) l_slot[i] = v; else g_slot[i] = v; };
 	typedef __attribute__((address_space(3))) uint16_t lds_u16;
-	lds_u16 *l_pat = (lds_u16 *)(dyn_lds + (((size_t)NB * 5 + 15) & ~(size_t)15));   // n_orient * 4096
-	lds_u32 *l_torg = (lds_u32 *)(l_pat + (TILED ? (size_t)a.n_orient * 4096 : 0)); // n_tiles
+	// position p of a tile at p + p / 16: consecutive lanes look up positions 16 apart (one block each), which would be
+	// 32 bytes = the same four banks for the whole wave; the pad entry per block spreads them over all banks
+	constexpr uint32_t PAT_STRIDE = 4096 + 256;
+	lds_u16 *l_pat = (lds_u16 *)(dyn_lds + (((size_t)NB * 5 + 15) & ~(size_t)15));   // n_orient * PAT_STRIDE
+	lds_u32 *l_torg = (lds_u32 *)(l_pat + (TILED ? (size_t)a.n_orient * PAT_STRIDE : 0)); // n_tiles
 	lds_u8 *l_tori = (lds_u8 *)(l_torg + (TILED ? a.n_tiles : 0));                   // n_tiles
 	if (TILED) {
-		for (int i = tid; i < a.n_orient * 4096; i += T) l_pat[i] = a.patterns[i];
+		// the encoder's pattern entries are swizzled LDS byte offsets (dy*128 + ((dx>>3 ^ dy&7) << 4) + (dx&7)*2); pass B wants
+		// the raster offset inside the tile, dy * width + dx (< 65536: launch_decode takes this path for widths <= 1024 only)
+		for (int i = tid; i < a.n_orient * 4096; i += T) {
+			const uint32_t pv = a.patterns[i];
+			const uint32_t dy = pv >> 7, dx = ((((pv >> 4) & 7u) ^ (dy & 7u)) << 3) | ((pv & 15u) >> 1);
+			const uint32_t o = (uint32_t)i >> 12, p = (uint32_t)i & 4095u;
+			l_pat[o * PAT_STRIDE + p + (p >> 4)] = (uint16_t)(dy * (uint32_t)a.width + dx);
+		}
 		for (int i = tid; i < a.n_tiles; i += T) { l_torg[i] = a.tile_org[i]; l_tori[i] = a.tile_orient[i]; }
 	}
 	// raster offset of traversal position pos
 	auto raster_of = [&](uint32_t pos) -> uint32_t {
 		if (TILED) {
 			const uint32_t tile = pos >> 12;
-			const uint32_t pv = l_pat[(uint32_t)l_tori[tile] * 4096u + (pos & 4095u)];  // dy*128 + ((dx>>3 ^ dy&7) << 4) + (dx&7)*2
-			const uint32_t dy = pv >> 7, dx = ((((pv >> 4) & 7u) ^ (dy & 7u)) << 3) | ((pv & 15u) >> 1);
-			return l_torg[tile] + dy * (uint32_t)a.width + dx;
+			const uint32_t p = pos & 4095u;
+			return l_torg[tile] + l_pat[(uint32_t)l_tori[tile] * PAT_STRIDE + p + (p >> 4)];
 		}
 		return lut ? (uint32_t)lut[pos] : pos;
 	};
@@ -386,12 +395,22 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 
 	// ------------------------------------------------------------------ pass B: pixels
 	if (!(s_status & CCT_ST_STREAM)) {
-		// every lane re-reads its segments and what pass A's scans told it about them: no barrier in this pass
+		// every lane re-reads its segments and what pass A's scans told it about them: no barrier in this pass; the loads
+		// of the next step are issued before this step's pixels are written
+		uint4 w_n = make_uint4(0, 0, 0, 0); uint32_t nxt_n = 0; int nvalid_n = 0;
+		uint2 pc_n = make_uint2(0, 0);
+		if (nsteps) { load_seg((uint32_t)tid * DEC_SEG, w_n, nxt_n, nvalid_n); pc_n = pcache[tid]; }
+#ifdef CCT_DEC_PROF
+		long long tb[4] = {0, 0, 0, 0}, tq = clock64();
+#define DECB(j) do { const long long t_ = clock64(); tb[j] += t_ - tq; tq = t_; } while (0)
+#else
+#define DECB(j) do {} while (0)
+#endif
 		for (uint32_t k = 0; k < nsteps; k++) {
 			const uint32_t seg_start = k * (uint32_t)T * DEC_SEG + (uint32_t)tid * DEC_SEG;
-			uint4 w; uint32_t nxt; int nvalid;
-			load_seg(seg_start, w, nxt, nvalid);
-			const uint2 pc = pcache[(size_t)k * T + tid];
+			const uint4 w = w_n; const uint32_t nxt = nxt_n; const int nvalid = nvalid_n;
+			const uint2 pc = pc_n;
+			if (k + 1 < nsteps) { load_seg(seg_start + (uint32_t)T * DEC_SEG, w_n, nxt_n, nvalid_n); pc_n = pcache[(size_t)(k + 1) * T + tid]; }
 			Parse p;
 			p.entry = pc.x >> 31; p.pix_base = pc.x & 0x7FFFFFFFu; p.val_base = (int32_t)pc.y;
 			// token structure of the segment as masks (see seg_masks): the loop below visits pixel tokens only
@@ -413,49 +432,101 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 				}
 				starts &= keep; pix &= keep; fulls &= keep;
 			}
+			DECB(0);
 			const uint32_t jm = starts & sm.J;
 			if (jm & (jm << 1)) flags |= CCT_ST_STREAM;  // two jump bytes in a row
 			if (nvalid > 0 && ((fulls >> (nvalid - 1)) & 1u) && seg_start + (uint32_t)nvalid >= Lr) flags |= CCT_ST_STREAM;  // second byte missing
-			// a lane's pixels fall into at most two stream slots: slot entry, partner and tile data are fetched once per slot
-			uint32_t cur_sl = 0xFFFFFFFFu, kind = 0, blk0 = 0, blk1 = 0;
-			uint32_t org0 = 0, org1 = 0, pat0 = 0, pat1 = 0;
-			for (uint32_t pm = pix; pm; pm &= pm - 1) {
-				const int i = __ffs((int)pm) - 1;
-				const uint32_t c = seg_byte(w, nxt, i);
-				if ((sm.S >> i) & 1u) val += tok_delta_short(c);
-				else if ((fulls >> i) & 1u) val += tok_delta_full(c, seg_byte(w, nxt, i + 1));
-				// (reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats)
-				if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
-				const uint32_t sl = ord / BS, t = ord % BS;
-				if (sl != cur_sl) {
-					cur_sl = sl;
-					const uint32_t ent = slot_rd(sl);
-					blk0 = ent & 0x3FFFFFFFu; kind = ent >> 30;
-					blk1 = kind ? blk0 + role_rd(blk0) : blk0;
+			if constexpr (BS >= 16) {
+				// A lane's <= 16 pixels fall into at most two stream slots: both slots' entry, partner and tile data are fetched
+				// before the loop.  The loop itself runs over the 16 byte positions with a compile-time index (a byte is a bit-field
+				// extract, not a select chain) and skips the positions that open no pixel token.
+				struct SlotInfo { uint32_t kind, blk0, blk1, org0, org1, pat0, pat1; };
+				auto slot_info = [&](uint32_t sl) {
+					SlotInfo si{0, 0, 0, 0, 0, 0, 0};
+					const uint32_t ent = slot_rd(min(sl, (uint32_t)NB - 1u));
+					si.blk0 = ent & 0x3FFFFFFFu; si.kind = ent >> 30;
+					si.blk1 = si.kind ? si.blk0 + role_rd(si.blk0) : si.blk0;
 					if (TILED) {
-						const uint32_t t0 = (blk0 * BS) >> 12, t1 = (blk1 * BS) >> 12;
-						org0 = l_torg[t0]; pat0 = (uint32_t)l_tori[t0] * 4096u;
-						org1 = l_torg[t1]; pat1 = (uint32_t)l_tori[t1] * 4096u;
+						const uint32_t t0 = (si.blk0 * BS) >> 12, t1 = (si.blk1 * BS) >> 12;
+						si.org0 = l_torg[t0]; si.pat0 = (uint32_t)l_tori[t0] * PAT_STRIDE;
+						si.org1 = l_torg[t1]; si.pat1 = (uint32_t)l_tori[t1] * PAT_STRIDE;
 					}
+					return si;
+				};
+				const uint32_t slA = ord / BS;
+				const SlotInfo A = slot_info(slA), B = slot_info(slA + 1u);
+				DECB(1);
+				const uint32_t ws[5] = {w.x, w.y, w.z, w.w, nxt};
+#pragma unroll
+				for (int i = 0; i < 16; i++) {
+					if (!((pix >> i) & 1u)) continue;
+					const uint32_t c = (ws[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+					const uint32_t c1 = (ws[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu;
+					// (reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats)
+					val += ((sm.S >> i) & 1u) ? tok_delta_short(c) : ((fulls >> i) & 1u) ? tok_delta_full(c, c1) : 0;
+					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
+					const uint32_t sl = ord / BS, t = ord % BS;
+					const bool inA = sl == slA;
+					const uint32_t kind = inA ? A.kind : B.kind;
+					uint32_t odd = 0, off = t;
+					if (kind) { const uint32_t mm = (kind - 1u) * BS + t; odd = mm & 1u; off = mm >> 1; }  // index inside the 2*bs interleave
+					const uint32_t blk = inA ? (odd ? A.blk1 : A.blk0) : (odd ? B.blk1 : B.blk0);
+					const uint32_t pos = blk * BS + off;
+					uint32_t ras;
+					if (TILED) {
+						const uint32_t org = inA ? (odd ? A.org1 : A.org0) : (odd ? B.org1 : B.org0);
+						const uint32_t pat = inA ? (odd ? A.pat1 : A.pat0) : (odd ? B.pat1 : B.pat0);
+						const uint32_t p = pos & 4095u;
+						ras = org + l_pat[pat + p + (p >> 4)];
+					} else ras = raster_of(pos);
+					out[ras] = (uint16_t)val;
+					ord++;
 				}
-				uint32_t pos, odd = 0;
-				if (kind == 0) pos = blk0 * BS + t;
-				else {
-					const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
-					odd = mm & 1u;
-					pos = (odd ? blk1 : blk0) * BS + (mm >> 1);
+			} else {
+				// a lane's pixels fall into at most two stream slots: slot entry, partner and tile data are fetched once per slot
+				uint32_t cur_sl = 0xFFFFFFFFu, kind = 0, blk0 = 0, blk1 = 0;
+				uint32_t org0 = 0, org1 = 0, pat0 = 0, pat1 = 0;
+				for (uint32_t pm = pix; pm; pm &= pm - 1) {
+					const int i = __ffs((int)pm) - 1;
+					const uint32_t c = seg_byte(w, nxt, i);
+					if ((sm.S >> i) & 1u) val += tok_delta_short(c);
+					else if ((fulls >> i) & 1u) val += tok_delta_full(c, seg_byte(w, nxt, i + 1));
+					// (reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats)
+					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
+					const uint32_t sl = ord / BS, t = ord % BS;
+					if (sl != cur_sl) {
+						cur_sl = sl;
+						const uint32_t ent = slot_rd(sl);
+						blk0 = ent & 0x3FFFFFFFu; kind = ent >> 30;
+						blk1 = kind ? blk0 + role_rd(blk0) : blk0;
+						if (TILED) {
+							const uint32_t t0 = (blk0 * BS) >> 12, t1 = (blk1 * BS) >> 12;
+							org0 = l_torg[t0]; pat0 = (uint32_t)l_tori[t0] * PAT_STRIDE;
+							org1 = l_torg[t1]; pat1 = (uint32_t)l_tori[t1] * PAT_STRIDE;
+						}
+					}
+					uint32_t pos, odd = 0;
+					if (kind == 0) pos = blk0 * BS + t;
+					else {
+						const uint32_t mm = (kind - 1u) * BS + t;  // index inside the 2*bs interleave
+						odd = mm & 1u;
+						pos = (odd ? blk1 : blk0) * BS + (mm >> 1);
+					}
+					uint32_t ras;
+					if (TILED) {
+						const uint32_t p = pos & 4095u;
+						ras = (odd ? org1 : org0) + l_pat[(odd ? pat1 : pat0) + p + (p >> 4)];
+					} else ras = raster_of(pos);
+					out[ras] = (uint16_t)val;
+					ord++;
 				}
-				uint32_t ras;
-				if (TILED) {
-					const uint32_t pv = l_pat[(odd ? pat1 : pat0) + (pos & 4095u)];  // dy*128 + ((dx>>3 ^ dy&7) << 4) + (dx&7)*2
-					const uint32_t dy = pv >> 7, dx = ((((pv >> 4) & 7u) ^ (dy & 7u)) << 3) | ((pv & 15u) >> 1);
-					ras = (odd ? org1 : org0) + dy * (uint32_t)a.width + dx;
-				} else ras = raster_of(pos);
-				out[ras] = (uint16_t)val;
-				ord++;
 			}
+			DECB(2);
 			if (flags) atomicOr(&s_status, flags);
 		}
+#ifdef CCT_DEC_PROF
+		if (s == 0 && tid == 0) printf("[decode prof] pass B wave 0: masks %lld slots %lld pixels %lld\n", tb[0], tb[1], tb[2]);
+#endif
 	}
 	__syncthreads();
 	DEC_STAMP();
@@ -475,8 +546,8 @@ hipError_t launch_decode(const DecArgs &a, int n, int block_size, int threads, h
 {
 	const size_t tab_bytes = (((size_t)a.NB * 5 + 15) & ~(size_t)15) + 16;
 	const bool tab_lds = tab_bytes <= 100 * 1024;
-	const size_t tile_bytes = (size_t)a.n_orient * 8192 + (size_t)a.n_tiles * 5 + 16;
-	const bool tiled = tab_lds && block_size == 16 && a.lut && a.n_tiles > 0 && tab_bytes + tile_bytes <= 144 * 1024;
+	const size_t tile_bytes = (size_t)a.n_orient * (4096 + 256) * 2 + (size_t)a.n_tiles * 5 + 16;
+	const bool tiled = tab_lds && block_size == 16 && a.lut && a.n_tiles > 0 && tab_bytes + tile_bytes <= 144 * 1024 && a.width <= 1024;
 	void (*k)(DecArgs) = nullptr;
 	switch (block_size) {
 	case 4: k = tab_lds ? decode_kernel<4, true> : decode_kernel<4, false>; break;
