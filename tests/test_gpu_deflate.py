@@ -216,3 +216,41 @@ def test_device_inflate_alone_reports_errors_per_stream(hip):
     for s_ in (bad_adler, truncated, bad_header, garbage):
         with pytest.raises(z.error):
             z.decompress(s_)
+
+
+def test_device_inflate_agrees_with_zlib_on_damaged_streams(hip):
+    """Error parity, not just happy-path parity: every single-bit flip of a few valid streams (dynamic, fixed and stored
+    blocks) either inflates to the same bytes on both sides or is refused by both -- invalid code sets (over-subscribed,
+    incomplete), bad block types, invalid distance / literal codes, distances too far back, stored-length mismatches,
+    truncations of the Adler trailer all come up this way."""
+    import zlib as z
+    rng = np.random.default_rng(11)
+    bases = [z.compress(bytes(rng.integers(0, 7, 900, dtype=np.uint8)) + b"abcabcabc" * 40, 9),
+             z.compress(b"the quick brown fox jumps over the lazy dog. " * 12, 9),
+             z.compressobj(9, z.DEFLATED, 15, 9, z.Z_FIXED).compress(b"fixed huffman block " * 30) + b""]
+    c = z.compressobj(9, z.DEFLATED, 15, 9, z.Z_FIXED)
+    bases[2] = c.compress(b"fixed huffman block " * 30) + c.flush()
+    c = z.compressobj(0)
+    bases.append(c.compress(bytes(range(200))) + c.flush())
+    streams, expect = [], []
+    for base in bases:
+        nbits = len(base) * 8
+        picks = range(nbits) if nbits <= 1600 else sorted(set(int(x) for x in rng.integers(0, nbits, 1600)))
+        for bit in picks:
+            s = bytearray(base)
+            s[bit >> 3] ^= 1 << (bit & 7)
+            s = bytes(s)
+            try:
+                d = z.decompressobj()
+                out = d.decompress(s, 1 << 16)
+                ok = d.eof and not d.unconsumed_tail  # zlib.decompress() semantics: the stream must be complete
+                want = out if ok else None
+            except z.error:
+                want = None
+            streams.append(s)
+            expect.append(want)
+    outs, status = hip.zlib_decompress_batch(streams, max_out=1 << 16, raise_errors=False)
+    bad = [(i, status[i]) for i, (got, want) in enumerate(zip(outs, expect))
+           if (want is None) != (got is None) or (want is not None and got != want)]
+    assert not bad, f"{len(bad)} of {len(streams)} damaged streams disagree with zlib, first {bad[:5]}"
+    assert sum(w is not None for w in expect) > 0 and sum(w is None for w in expect) > len(expect) // 2
