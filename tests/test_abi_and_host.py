@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -91,3 +92,58 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{fn} imports the oracle"
                 assert not re.search(r"#\s*include[^\n]*oracle", src), f"{fn} includes oracle code"
                 assert "libcompact_oracle" not in src and "libdeflate_model" not in src, f"{fn} loads an oracle library"
+
+
+def test_options_round_trip_without_a_device():
+    """cct_set_option / cct_get_option are host state: they work before (and without) a device, clamp what they must and
+    refuse what they do not know."""
+    import ctypes as C
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    v = C.c_int(-1)
+    for key, given, want in ((b"encode_slots", 2, 2), (b"encode_slots", 7, 2), (b"encode_slots", 0, 1), (b"tile_path", 3, 3),
+                             (b"tile_path", 9, 1), (b"device_inflate", 5, 1), (b"deflate_graph", 0, 0), (b"deflate_graph", 1, 1)):
+        assert L.cct_set_option(key, given) == 0
+        assert L.cct_get_option(key, C.byref(v)) == 0 and v.value == want, (key, given, v.value)
+    assert L.cct_set_option(b"encode_slots", 2) == 0 and L.cct_set_option(b"tile_path", 1) == 0
+    assert L.cct_set_option(b"deflate_ways", 2) != 0      # removed in round 2
+    assert L.cct_set_option(b"no_such_option", 1) != 0
+    assert L.cct_get_option(b"no_such_option", C.byref(v)) != 0
+
+
+def test_bench_traffic_figure_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
+    """bench.py prints the PMC traffic of the transform+pack stage only while the SHA-1 stored with it is the SHA-1 of
+    encode_pipe.hip; and the summary committed under profiles/ belongs to the source committed next to it."""
+    import hashlib
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(bench.PIPE_SRC, "rb") as f:
+        sha = hashlib.sha1(f.read()).hexdigest()
+    with open(bench.PMC_JSON) as f:
+        pmc = json.load(f)
+    assert pmc["source_sha1"] == sha, "encode_pipe.hip changed after the PMC passes: re-run tools/gpu_round_end.sh + collect_profiles.py"
+    traffic, src = bench.pmc_traffic()
+    assert traffic == pmc["traffic_bytes_per_launch"] and traffic > pmc["algorithmic_read_bytes"] and "r02_pmc_encode.json" in src
+    stale = tmp_path / "pmc.json"
+    stale.write_text(json.dumps(dict(pmc, source_sha1="0" * 40)))
+    monkeypatch.setattr(bench, "PMC_JSON", str(stale))
+    traffic, src = bench.pmc_traffic()
+    assert traffic is None and src.startswith("stale")
+    monkeypatch.setattr(bench, "PMC_JSON", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic() == (None, None)
+
+
+def test_bench_workloads_and_sharding_follow_baseline_json():
+    """The bench configurations are BASELINE.json's configs[1], [3], [4]; the corpus of configs[2] shards as DESIGN 8 says."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from cct_hip.parallel import shard_range
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert len(base["configs"]) >= 5
+    assert bench.WORKLOADS == {2: (512, 256), 4: (1024, 512), 5: (512, 256)}
+    sizes = [shard_range(3954, r, 8) for r in range(8)]
+    assert [b - a for a, b in sizes] == [495, 495, 494, 494, 494, 494, 494, 494]
+    assert sizes[0][0] == 0 and sizes[-1][1] == 3954 and all(sizes[i][1] == sizes[i + 1][0] for i in range(7))
