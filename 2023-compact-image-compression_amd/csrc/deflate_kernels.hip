@@ -811,8 +811,10 @@ struct TreeScratch {  // one block's working set, in LDS
 	uint16_t next_code[MAX_BITS + 1];
 	int heap_len, heap_max, max_code, overflow, lmax, dmax;
 	uint32_t opt_len, static_len, dyn_body_bits;
-	// dynamic-block header (14 + 3*19 + up to 316 * 14 bits): lane 0 keeps the open word in registers, full words go to HBM
-	uint64_t hdr_acc; uint32_t hdr_nbits; uint32_t *hdr_out;
+	// dynamic-block header (14 + 3*19 + up to 316 * 14 bits), assembled by the whole wave with LDS atomics
+	uint32_t hdr_bits[160];
+	uint32_t hdr_nbits;
+	int ntok, btype, max_blindex;
 	// staged tables
 	uint8_t extra_l[29], extra_d[30], extra_bl[19], bl_order[19];
 	// histogram phase only (see above)
@@ -820,8 +822,12 @@ struct TreeScratch {  // one block's working set, in LDS
 	__device__ __forceinline__ uint32_t *hist_d() { return heap + L_CODES + 2; }
 	__device__ __forceinline__ uint8_t *length_code() { return reinterpret_cast<uint8_t *>(dad); }
 	__device__ __forceinline__ uint8_t *dist_code() { return reinterpret_cast<uint8_t *>(dad) + 256; }
+	// header phase: the run-length tokens of the two code-length sequences (scan_tree records them, the wave emits them);
+	// dad[] of the literal/length tree is free by then.  token = symbol 0..18 | extra-bits value << 5
+	__device__ __forceinline__ uint16_t *tok() { return dad; }
 };
-static_assert(sizeof(TreeScratch) <= 7380, "13 tree waves per CU need <= 7.38 KB each");
+static_assert(sizeof(TreeScratch) <= 8192, "13 tree waves per CU: keep the working set around 8 KB");
+static_assert(HEAP_SIZE >= L_CODES + D_CODES, "token list fits dad[]");
 static_assert((HEAP_SIZE + 1) * 4 >= (L_CODES + 2 + D_CODES) * 4 && HEAP_SIZE * 2 >= 768, "aliases fit");
 // tr_static_init's literal/length code lengths (trees.c:255-258)
 __device__ __forceinline__ uint32_t static_llen(int n) { return n <= 143 ? 8u : n <= 255 ? 9u : n <= 279 ? 7u : 8u; }
@@ -876,23 +882,27 @@ __device__ __forceinline__ void pqdownheap(TreeScratch &S, int k, int hl)
 // levels still execute, reading harmlessly and storing to the unused heap[0].
 __device__ __forceinline__ uint32_t sift_root(TreeScratch &S, uint32_t v, int hl, int levels)
 {
-	const uint32_t vk = v >> 10;
-	uint32_t rootv = v;
-	uint32_t k = 1, moving = 1;
-	for (int l = 0; l < levels; l++) {
+	// smaller(a, b) of trees.c is (a >> 10) <= (b >> 10) on these entries, i.e. a <= (b | 1023): one OR instead of two shifts
+	if (levels == 0) { S.heap[1] = v; return v; }  // (uniform) a heap of one entry
+	// first level, hole at the root: what lands there is the value to return
+	const uint2 p0 = *reinterpret_cast<const uint2 *>(&S.heap[2]);
+	uint32_t right = (2 < hl && p0.y <= (p0.x | 1023u)) ? 1u : 0u;
+	uint32_t e = right ? p0.y : p0.x;
+	uint32_t moving = v > (e | 1023u) ? 1u : 0u;  // hl >= 2 here
+	const uint32_t rootv = moving ? e : v;
+	S.heap[1] = rootv;
+	uint32_t k = 2u + right;
+	for (int l = 1; l < levels; l++) {
 		const uint32_t j = k << 1;
 		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[min(j, (uint32_t)(HEAP_SIZE - 1))]);
-		const uint32_t right = (j < (uint32_t)hl && (pr.y >> 10) <= (pr.x >> 10)) ? 1u : 0u;
-		const uint32_t e = right ? pr.y : pr.x;
-		const uint32_t go = (moving && j <= (uint32_t)hl && vk > (e >> 10)) ? 1u : 0u;
-		const uint32_t put = go ? e : v;   // what the hole at k receives: the smaller child, or v (which then stays there)
-		S.heap[moving ? k : 0u] = put;
-		rootv = (moving && k == 1u) ? put : rootv;
+		right = (j < (uint32_t)hl && pr.y <= (pr.x | 1023u)) ? 1u : 0u;
+		e = right ? pr.y : pr.x;
+		const uint32_t go = (moving && j <= (uint32_t)hl && v > (e | 1023u)) ? 1u : 0u;
+		S.heap[moving ? k : 0u] = go ? e : v;  // the hole at k receives the smaller child, or v (which then stays there)
 		k = go ? j + right : k;
 		moving = go;
 	}
 	S.heap[moving ? k : 0u] = v;
-	rootv = (moving && k == 1u) ? v : rootv;
 	return rootv;
 }
 
@@ -1089,47 +1099,63 @@ __device__ void scan_tree(TreeScratch &S, const TreeView &t, int max_code)
 	int n, prevlen = -1, curlen, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
 	if (nextlen == 0) { max_count = 138; min_count = 3; }
 	t.len[max_code + 1] = 0xffff;
+	// the tokens send_tree (trees.c:757-800) would write for this sequence are recorded on the way: the same walk, once
+	uint16_t *tk = S.tok();
+	int nt = S.ntok;
 	for (n = 0; n <= max_code; n++) {
 		curlen = nextlen; nextlen = t.len[n + 1];
 		if (++count < max_count && curlen == nextlen) continue;
-		else if (count < min_count) S.bfreq[curlen] += (uint16_t)count;
-		else if (curlen != 0) { if (curlen != prevlen) S.bfreq[curlen]++; S.bfreq[16]++; }
-		else if (count <= 10) S.bfreq[17]++;
-		else S.bfreq[18]++;
+		else if (count < min_count) {
+			S.bfreq[curlen] += (uint16_t)count;
+			for (int c = 0; c < count; c++) tk[nt++] = (uint16_t)curlen;
+		} else if (curlen != 0) {
+			if (curlen != prevlen) { S.bfreq[curlen]++; tk[nt++] = (uint16_t)curlen; count--; }
+			S.bfreq[16]++; tk[nt++] = (uint16_t)(16 | ((count - 3) << 5));
+		} else if (count <= 10) { S.bfreq[17]++; tk[nt++] = (uint16_t)(17 | ((count - 3) << 5)); }
+		else { S.bfreq[18]++; tk[nt++] = (uint16_t)(18 | ((count - 11) << 5)); }
 		count = 0; prevlen = curlen;
 		if (nextlen == 0) { max_count = 138; min_count = 3; }
 		else if (curlen == nextlen) { max_count = 6; min_count = 3; }
 		else { max_count = 7; min_count = 4; }
 	}
+	S.ntok = nt;
 }
 
-__device__ __forceinline__ void hdr_put(TreeScratch &S, uint32_t value, int length)
+// `n` bits of `value` at bit position `pos` of the (zeroed) header image
+__device__ __forceinline__ void hdr_or(TreeScratch &S, uint32_t pos, uint32_t value, uint32_t n)
 {
-	const uint32_t pos = S.hdr_nbits, sh = pos & 31;
-	uint64_t acc = S.hdr_acc | ((uint64_t)value << sh);
-	if (sh + length >= 32) { S.hdr_out[pos >> 5] = (uint32_t)acc; acc >>= 32; }
-	S.hdr_acc = acc;
-	S.hdr_nbits = pos + length;
+	const uint32_t w = pos >> 5, sh = pos & 31u;
+	atomicOr(&S.hdr_bits[w], value << sh);
+	if (sh + n > 32u) atomicOr(&S.hdr_bits[w + 1], value >> (32u - sh));
 }
 
-__device__ void send_tree(TreeScratch &S, const TreeView &t, int max_code)
+// (whole wave) the header of a dynamic block (trees.c send_all_trees): HLIT, HDIST, HCLEN, the code lengths of the
+// bit-length alphabet in bl_order, then the tokens scan_tree recorded, each at its prefix-summed bit offset
+__device__ void send_header(TreeScratch &S)
 {
-	int n, prevlen = -1, curlen, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
-	if (nextlen == 0) { max_count = 138; min_count = 3; }
-	for (n = 0; n <= max_code; n++) {
-		curlen = nextlen; nextlen = t.len[n + 1];
-		if (++count < max_count && curlen == nextlen) continue;
-		else if (count < min_count) { do { hdr_put(S, S.bcode[curlen], S.blen[curlen]); } while (--count != 0); }
-		else if (curlen != 0) {
-			if (curlen != prevlen) { hdr_put(S, S.bcode[curlen], S.blen[curlen]); count--; }
-			hdr_put(S, S.bcode[16], S.blen[16]); hdr_put(S, (uint32_t)(count - 3), 2);
-		} else if (count <= 10) { hdr_put(S, S.bcode[17], S.blen[17]); hdr_put(S, (uint32_t)(count - 3), 3); }
-		else { hdr_put(S, S.bcode[18], S.blen[18]); hdr_put(S, (uint32_t)(count - 11), 7); }
-		count = 0; prevlen = curlen;
-		if (nextlen == 0) { max_count = 138; min_count = 3; }
-		else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-		else { max_count = 7; min_count = 4; }
+	const int lane = threadIdx.x;
+	const int nbl = S.max_blindex + 1;
+	if (lane == 0) hdr_or(S, 0, (uint32_t)(S.lmax + 1 - 257) | ((uint32_t)(S.dmax + 1 - 1) << 5) | ((uint32_t)(nbl - 4) << 10), 14);
+	if (lane < nbl) hdr_or(S, 14u + 3u * (uint32_t)lane, S.blen[S.bl_order[lane]], 3);
+	uint32_t base = 14u + 3u * (uint32_t)nbl;
+	const uint16_t *tk = S.tok();
+	const int nt = S.ntok;
+	for (int c0 = 0; c0 < nt; c0 += 64) {
+		const int i = c0 + lane;
+		uint32_t nbits = 0, val = 0;
+		if (i < nt) {
+			const uint32_t sym = tk[i] & 31u, ex = tk[i] >> 5;
+			const uint32_t cl = S.blen[sym];
+			nbits = cl + S.extra_bl[sym];
+			val = (uint32_t)S.bcode[sym] | (ex << cl);
+		}
+		uint32_t inc = nbits;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+		if (nbits) hdr_or(S, base + inc - nbits, val, nbits);
+		base += (uint32_t)__shfl((int)inc, 63, 64);
 	}
+	if (lane == 0) S.hdr_nbits = base;
 }
 
 // One wave per TREE_BLOCKS consecutive blocks of a slice: histograms + trees (trees.c _tr_flush_block).  The serial
@@ -1167,7 +1193,6 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		const uint32_t first = (uint32_t)m * BLOCK_SYMS;
 		const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
 		const uint32_t *sym = a.sym + (size_t)s * a.in_stride + first;
-		BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m);
 		for (int i = lane; i < HEAP_SIZE; i += 64) { S.freq[i] = 0; S.len[i] = 0; }
 		for (int i = lane; i < L_CODES + 2; i += 64) S.code[i] = 0;
 		for (int i = lane; i < 2 * D_CODES + 1; i += 64) { S.dfreq[i] = 0; S.dlen[i] = 0; S.ddad[i] = 0; }
@@ -1203,7 +1228,8 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		__syncthreads();
 		for (int i = lane; i < L_CODES; i += 64) S.freq[i] = (uint16_t)hl[i];
 		if (lane < D_CODES) S.dfreq[lane] = (uint16_t)hd[lane];
-		if (lane == 0) { S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0; S.hdr_acc = 0; S.hdr_out = bt->hdr_bits; }
+		for (int i = lane; i < 160; i += 64) S.hdr_bits[i] = 0;
+		if (lane == 0) { S.opt_len = 0; S.static_len = 0; S.hdr_nbits = 0; S.ntok = 0; S.btype = 0; S.max_blindex = 0; }
 		__syncthreads();
 		if (lane == 0) S.freq[END_BLOCK] = 1;
 		for (int i = lane; i < HEAP_SIZE; i += 64) S.dad[i] = 0;  // held the code tables of the histogram
@@ -1246,7 +1272,6 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		const uint32_t nsym = last ? T - first : (uint32_t)BLOCK_SYMS;
 		const uint32_t in_begin = m == 0 ? 0u : bend[m - 1];
 		const uint32_t in_end = last ? L : bend[m];
-		const int lmax = S.lmax, dmax = S.dmax;
 		int max_blindex;
 		for (max_blindex = BL_CODES - 1; max_blindex >= 3; max_blindex--)
 			if (S.blen[S.bl_order[max_blindex]] != 0) break;
@@ -1264,19 +1289,22 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		} else if (static_lenb == opt_lenb) {
 			bm.type = 1; bm.hdr_nbits = 0; bm.body_bits = S.static_len;
 		} else {
-			bm.type = 2;
-			hdr_put(S, (uint32_t)(lmax + 1 - 257), 5);
-			hdr_put(S, (uint32_t)(dmax + 1 - 1), 5);
-			hdr_put(S, (uint32_t)(max_blindex + 1 - 4), 4);
-			for (int rank = 0; rank < max_blindex + 1; rank++) hdr_put(S, S.blen[S.bl_order[rank]], 3);
-#pragma unroll 1
-			for (int w = 0; w < 2; w++) send_tree(S, view_of(S, w), w ? dmax : lmax);
-			if (S.hdr_nbits & 31u) S.hdr_out[S.hdr_nbits >> 5] = (uint32_t)S.hdr_acc;  // the open word
-			bm.hdr_nbits = S.hdr_nbits;
+			bm.type = 2; bm.hdr_nbits = 0;  // hdr_nbits follows below, once the wave has written the header
 			bm.body_bits = S.dyn_body_bits;
 		}
+		S.btype = (int)bm.type; S.max_blindex = max_blindex;
 		meta[m] = bm;
 		if (m == 0) a.n_blocks[s] = nblocks;
+	}
+	__syncthreads();
+	for (int q = 0; q < nb; q++) {
+		TreeScratch &S = S4[q];
+		if (S.btype != 2) continue;  // (uniform)
+		send_header(S);
+		__syncthreads();
+		BlockTables *bt = a.block_tables + ((size_t)s * a.max_blocks + m0 + q);
+		for (int i = lane; i * 32 < (int)S.hdr_nbits; i += 64) bt->hdr_bits[i] = S.hdr_bits[i];
+		if (lane == 0) meta[m0 + q].hdr_nbits = S.hdr_nbits;
 	}
 	__syncthreads();
 	TREE_STAMP();
