@@ -22,13 +22,10 @@
 
 #include "../../include/compact_hip.h"
 #include "cct_internal.h"
-
-struct cct_unique_id_t { char internal[CCT_COMM_ID_BYTES]; };  // ncclUniqueId: passed to ncclCommInitRank by value
+#include "host.h"
 
 namespace cct {
 bool gilbert_table(int width, int height, int32_t *out);
-
-namespace {
 
 thread_local char g_err[512] = "";
 
@@ -41,33 +38,9 @@ int fail(int code, const char *fmt, ...)
 	return code;
 }
 
-#define HIP_TRY(expr)                                                                          \
-	do {                                                                                         \
-		hipError_t e_ = (expr);                                                                    \
-		if (e_ != hipSuccess)                                                                      \
-			return fail(CCT_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                \
-	} while (0)
+std::mutex g_mu;
 
-struct DevBuf {  // grow-only device (or pinned host) buffer
-	void *p = nullptr;
-	size_t cap = 0;
-	bool pinned_host = false;
-	int ensure(size_t bytes)
-	{
-		if (bytes <= cap) return CCT_OK;
-		release();
-		const size_t want = bytes + bytes / 8 + 4096;
-		hipError_t e = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-		if (e != hipSuccess) { p = nullptr; cap = 0; return fail(CCT_E_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); }
-		cap = want;
-		return CCT_OK;
-	}
-	void release()
-	{
-		if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); }
-		p = nullptr; cap = 0;
-	}
-};
+namespace {
 
 struct ShapeTables {  // everything that depends on (width, height) only; lives in HBM
 	int32_t *d_lut = nullptr;  // traversal order O[N]
@@ -174,7 +147,6 @@ void reset_ctx() { g_ctx = Context(); delete[] g_enc; g_enc = new EncSlot[N_ENC_
 // timings of the calling thread's most recent batch call (cct_last_timings): per thread, so that an encode and a
 // decode driven from two threads do not overwrite each other's numbers
 thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
-std::mutex g_mu;      // device context, main stream (and with it encode slot 0), every plumbing call
 std::mutex g_mu1;     // encode slot 1
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
 std::mutex g_mu_dec;  // one cct_decode_batch at a time; its host INFLATE phase runs outside g_mu so that
@@ -195,7 +167,9 @@ struct DrainOnExit {
 	void disarm() { armed = false; }
 };
 
-int ensure_ctx(int device = -1)
+}  // namespace
+
+int ensure_ctx(int device)
 {
 	if (g_ctx.ready && g_ctx.pid != getpid()) {
 		// A child forked AFTER the parent initialised the device inherits a HIP runtime it cannot use (ROCm does not
@@ -258,6 +232,12 @@ int ensure_ctx(int device = -1)
 	g_ctx.ready = true;
 	return CCT_OK;
 }
+
+hipStream_t main_stream() { return g_ctx.stream; }
+int bound_device() { return g_ctx.device; }
+bool forked_after_init() { return g_ctx.ready && g_ctx.pid != getpid(); }
+
+namespace {
 
 // Tables of the staged pipeline.  Inside every 64x64 tile the traversal must walk aligned 4x4-pixel blocks (16
 // positions each), and every block must be walked quadrant by quadrant (2x2 pixels, 4 positions each) with quarter 0
@@ -770,44 +750,6 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	return CCT_OK;
 }
 
-// ---- RCCL through dlopen: the library carries no link-time dependency on librccl (573 MB) ------------------
-struct Rccl {
-	void *h = nullptr;
-	int (*GetUniqueId)(void *) = nullptr;
-	int (*CommInitRank)(void **, int, cct_unique_id_t, int) = nullptr;
-	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-	int (*CommDestroy)(void *) = nullptr;
-	const char *(*GetErrorString)(int) = nullptr;
-	void *comm = nullptr;
-	int rank = -1, world = 0;
-	DevBuf d_send, d_recv;
-	// the collective has a stream and a mutex of its own: on the main stream the gather of a few hundred sizes would queue
-	// behind the ten milliseconds of kernels of the encode batch in slot 0, once per step
-	hipStream_t stream = nullptr;
-	std::mutex mu;
-} g_rccl;
-
-int rccl_load()
-{
-	if (g_rccl.h) return CCT_OK;
-	void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-	if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if (!h) return fail(CCT_E_DEVICE, "cannot load librccl: %s", dlerror());
-	g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-	g_rccl.CommInitRank = (int (*)(void **, int, cct_unique_id_t, int))dlsym(h, "ncclCommInitRank");
-	g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
-	g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-	g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-	if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) { dlclose(h); return fail(CCT_E_DEVICE, "librccl lacks an expected symbol"); }
-	g_rccl.h = h;
-	return CCT_OK;
-}
-int rccl_fail(const char *what, int rc)
-{
-	return fail(CCT_E_DEVICE, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
-}
-
 }  // namespace
 }  // namespace cct
 
@@ -846,12 +788,7 @@ int cct_shutdown(void)
 		if (E.stream_copy) (void)hipStreamDestroy(E.stream_copy);
 		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
 	}
-	{
-		std::lock_guard<std::mutex> lkc(g_rccl.mu);
-		if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; g_rccl.rank = -1; g_rccl.world = 0; }
-		g_rccl.d_send.release(); g_rccl.d_recv.release();
-		if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
-	}
+	comm_release();
 	for (auto &kv : g_ctx.luts) {
 		ShapeTables &t = kv.second;
 		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
@@ -1541,135 +1478,6 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		}
 	}
 	return first;
-}
-
-int cct_comm_unique_id(void *id128)
-{
-	if (!id128) return fail(CCT_E_ARG, "null id");
-	std::lock_guard<std::mutex> lk(g_mu);
-	int rc = ensure_ctx();
-	if (rc || (rc = rccl_load())) return rc;
-	cct_unique_id_t id;
-	const int r = g_rccl.GetUniqueId(&id);
-	if (r) return rccl_fail("ncclGetUniqueId", r);
-	memcpy(id128, &id, CCT_COMM_ID_BYTES);
-	return CCT_OK;
-}
-
-int cct_comm_init(const void *id128, int rank, int world)
-{
-	if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(CCT_E_ARG, "bad communicator arguments");
-	std::lock_guard<std::mutex> lk(g_mu);
-	int rc = ensure_ctx();
-	if (rc || (rc = rccl_load())) return rc;
-	if (g_rccl.comm) return fail(CCT_E_ARG, "a communicator already exists");
-	cct_unique_id_t id;
-	memcpy(&id, id128, CCT_COMM_ID_BYTES);
-	std::lock_guard<std::mutex> lkc(g_rccl.mu);
-	if (!g_rccl.stream) HIP_TRY(hipStreamCreateWithFlags(&g_rccl.stream, hipStreamNonBlocking));
-	const int r = g_rccl.CommInitRank(&g_rccl.comm, world, id, rank);
-	if (r) { g_rccl.comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
-	g_rccl.rank = rank; g_rccl.world = world;
-	return CCT_OK;
-}
-
-int cct_comm_info(int *rank, int *world)
-{
-	std::lock_guard<std::mutex> lk(g_rccl.mu);
-	if (rank) *rank = g_rccl.comm ? g_rccl.rank : -1;
-	if (world) *world = g_rccl.comm ? g_rccl.world : 0;
-	return CCT_OK;
-}
-
-int cct_allgather_u32(const uint32_t *h_local, int n_local, int max_local, uint32_t *h_all)
-{
-	if (n_local < 0 || max_local < n_local || (n_local && !h_local) || !h_all) return fail(CCT_E_ARG, "bad all-gather arguments");
-	std::lock_guard<std::mutex> lk(g_rccl.mu);
-	if (!g_rccl.comm) {
-		for (int i = 0; i < max_local; i++) h_all[i] = i < n_local ? h_local[i] : 0u;
-		return CCT_OK;
-	}
-	if (g_ctx.pid != getpid()) return fail(CCT_E_DEVICE, "this process was forked after the communicator was created");
-	HIP_TRY(hipSetDevice(g_ctx.device));
-	int rc;
-	const size_t bytes = (size_t)std::max(max_local, 1) * 4;
-	if ((rc = g_rccl.d_send.ensure(bytes)) || (rc = g_rccl.d_recv.ensure(bytes * g_rccl.world))) return rc;
-	hipStream_t st = g_rccl.stream;
-	HIP_TRY(hipMemsetAsync(g_rccl.d_send.p, 0, bytes, st));
-	if (n_local) HIP_TRY(hipMemcpyAsync(g_rccl.d_send.p, h_local, (size_t)n_local * 4, hipMemcpyHostToDevice, st));
-	const int r = g_rccl.AllGather(g_rccl.d_send.p, g_rccl.d_recv.p, (size_t)max_local, 3 /* ncclUint32 */, g_rccl.comm, st);
-	if (r) return rccl_fail("ncclAllGather", r);
-	HIP_TRY(hipMemcpyAsync(h_all, g_rccl.d_recv.p, (size_t)max_local * 4 * g_rccl.world, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	return CCT_OK;
-}
-
-int cct_comm_destroy(void)
-{
-	std::lock_guard<std::mutex> lk(g_rccl.mu);
-	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
-	g_rccl.rank = -1; g_rccl.world = 0;
-	g_rccl.d_send.release(); g_rccl.d_recv.release();
-	if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
-	return CCT_OK;
-}
-
-size_t cct_packbits_bound(size_t n_bytes) { return 2 * n_bytes + 2; }  // a byte opens a chunk at worst: two output bytes each
-
-static int packbits_batch(bool encode, const uint8_t *h_in, const uint64_t *h_offsets, int n, int delta, uint8_t *h_out,
-                          size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status)
-{
-	if (n < 0 || !h_offsets || (n > 0 && (!h_in || !h_out || !h_out_sizes))) return fail(CCT_E_ARG, "bad argument");
-	if (n == 0) return CCT_OK;
-	std::lock_guard<std::mutex> lk(g_mu);
-	int rc = ensure_ctx();
-	if (rc) return rc;
-	const size_t total = (size_t)h_offsets[n];
-	size_t longest = 0;
-	for (int i = 0; i < n; i++) {
-		if (h_offsets[i + 1] < h_offsets[i]) return fail(CCT_E_ARG, "offsets must not decrease");
-		longest = std::max(longest, (size_t)(h_offsets[i + 1] - h_offsets[i]));
-	}
-	if (encode && out_stride < cct_packbits_bound(longest)) return fail(CCT_E_CAP, "out_stride %zu below cct_packbits_bound(%zu)", out_stride, longest);
-	DevBuf d_in, d_offs, d_ws, d_out, d_sizes, d_status;
-	auto release = [&] { d_in.release(); d_offs.release(); d_ws.release(); d_out.release(); d_sizes.release(); d_status.release(); };
-	if ((rc = d_in.ensure(total + 16)) || (rc = d_offs.ensure((size_t)(n + 1) * 8)) || (rc = d_ws.ensure((total + 1) * 4)) ||
-	    (rc = d_out.ensure((size_t)n * out_stride + 16)) || (rc = d_sizes.ensure((size_t)n * 4)) || (rc = d_status.ensure((size_t)n * 4))) { release(); return rc; }
-	hipError_t e = hipSuccess;
-	auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
-	if (total) step(hipMemcpyAsync(d_in.p, h_in, total, hipMemcpyHostToDevice, g_ctx.stream));
-	step(hipMemcpyAsync(d_offs.p, h_offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, g_ctx.stream));
-	step(hipMemsetAsync(d_status.p, 0, (size_t)n * 4, g_ctx.stream));
-	if (encode) step(launch_packbits_encode((const uint8_t *)d_in.p, (const uint64_t *)d_offs.p, n, delta, (uint32_t *)d_ws.p, (uint8_t *)d_out.p,
-	                                        out_stride, (uint32_t *)d_sizes.p, g_ctx.stream));
-	else step(launch_packbits_decode((const uint8_t *)d_in.p, (const uint64_t *)d_offs.p, n, delta, (uint8_t *)d_out.p, out_stride,
-	                                 (uint32_t *)d_sizes.p, (uint32_t *)d_status.p, g_ctx.stream));
-	step(hipMemcpyAsync(h_out_sizes, d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-	std::vector<uint32_t> st(n, 0);
-	step(hipMemcpyAsync(st.data(), d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-	step(hipStreamSynchronize(g_ctx.stream));
-	int first = CCT_OK;
-	if (e == hipSuccess)
-		for (int i = 0; i < n && e == hipSuccess; i++) {
-			if (h_status) h_status[i] = st[i];
-			if (st[i] && !first) first = (int)st[i];
-			if (!st[i] && h_out_sizes[i]) e = hipMemcpy(h_out + (size_t)i * out_stride, (const uint8_t *)d_out.p + (size_t)i * out_stride, h_out_sizes[i], hipMemcpyDeviceToHost);
-		}
-	release();
-	if (e != hipSuccess) return fail(CCT_E_DEVICE, "packbits: %s", hipGetErrorString(e));
-	return first ? fail(first, "packbits decode: string rejected") : CCT_OK;
-}
-
-int cct_packbits_encode_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, int delta_transform, uint8_t *h_out,
-                              size_t out_stride, uint32_t *h_out_sizes)
-{
-	return packbits_batch(true, h_in, h_offsets, n, delta_transform, h_out, out_stride, h_out_sizes, nullptr);
-}
-
-int cct_packbits_decode_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, int delta_transform, uint8_t *h_out,
-                              size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status)
-{
-	return packbits_batch(false, h_in, h_offsets, n, delta_transform, h_out, out_stride, h_out_sizes, h_status);
 }
 
 int cct_last_timings(float *out6)
