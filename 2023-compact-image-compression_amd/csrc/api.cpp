@@ -971,6 +971,160 @@ int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int heigh
 	                             d_payload_sizes, d_status, d_stats, d_roles);
 }
 
+// ---- pieces of cct_encode_batch / cct_encode_batch_packed -------------------------------------------------------------
+
+// take a free encode slot (see EncSlot): the first caller gets slot 0, one that arrives while it is busy slot 1
+static EncSlot &acquire_encode_slot(std::unique_lock<std::mutex> &lk)
+{
+	std::mutex *const slot_mu[N_ENC_SLOTS] = {&g_mu, &g_mu1};
+	const int nslots = std::max(1, std::min(g_ctx.enc_slots, N_ENC_SLOTS));
+	for (;;) {
+		for (int k = 0; k < nslots; k++) {
+			std::unique_lock<std::mutex> t(*slot_mu[k], std::try_to_lock);
+			if (t.owns_lock()) { lk = std::move(t); return g_enc[k]; }
+		}
+		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	}
+}
+
+// core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
+static void make_header13(uint8_t hdr13[13], const char magic[4], int width, int height, int channels, int bytes_per_channel,
+                          uint32_t flags)
+{
+	hdr13[0] = (uint8_t)magic[0]; hdr13[1] = (uint8_t)magic[1]; hdr13[2] = (uint8_t)magic[2]; hdr13[3] = (uint8_t)magic[3];
+	hdr13[4] = (uint8_t)((width >> 8) & 0xFF); hdr13[5] = (uint8_t)(width & 0xFF);
+	hdr13[6] = (uint8_t)((height >> 8) & 0xFF); hdr13[7] = (uint8_t)(height & 0xFF);
+	hdr13[8] = (uint8_t)(channels & 0xFF); hdr13[9] = (uint8_t)(bytes_per_channel & 0xFF);
+	hdr13[10] = (flags & CCT_FLAG_FRACTAL) ? 1 : 0;
+	hdr13[11] = (flags & CCT_FLAG_SEGMENTATION) ? 1 : 0;
+	hdr13[12] = (flags & CCT_FLAG_DEFLATE) ? 1 : 0;
+}
+
+// One DEFLATE pass worth of files (nc of them, sizes osz[], in E.z_out at stride zstride) on their way to the caller.
+struct FilesOut {
+	EncSlot &E;
+	int nc;
+	const uint32_t *osz;     // file sizes (host)
+	size_t zstride;
+	size_t exact;            // sum of the sizes
+	std::vector<size_t> offs;  // 16-byte aligned offsets of the files in a strided-pack buffer
+};
+
+// archive layout, whole batch, page-locked destination: pack into one of two device buffers, hand the copy to the copy
+// stream and give the slot back (lk) before waiting for it -- the next batch's kernels start while these files travel
+static int files_to_pinned_archive_async(FilesOut &f, uint8_t *h_dst, std::unique_lock<std::mutex> &lk, hipEvent_t *done)
+{
+	EncSlot &E = f.E;
+	int rc;
+	const unsigned slot = E.pack_slot++ & 1u;
+	if (!E.stream_copy) {
+		HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
+		for (int k = 0; k < 2; k++) {
+			HIP_TRY(hipEventCreateWithFlags(&E.ev_pack[k], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
+			HIP_TRY(hipEventRecord(E.ev_copied[k], E.stream_copy));
+		}
+	}
+	const size_t cap = f.offs[f.nc] + 16;  // the pack kernel works in 16-byte units
+	if (E.z_packed2[slot].cap < cap) HIP_TRY(hipEventSynchronize(E.ev_copied[slot]));  // about to be reallocated
+	if ((rc = E.z_packed2[slot].ensure(cap))) return rc;
+	HIP_TRY(hipStreamWaitEvent(E.stream, E.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
+	HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, f.zstride, (const uint32_t *)E.z_outsizes.p, f.nc,
+	                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed2[slot].p, 1, E.stream));
+	HIP_TRY(hipEventRecord(E.ev_pack[slot], E.stream));
+	HIP_TRY(hipStreamWaitEvent(E.stream_copy, E.ev_pack[slot], 0));
+	HIP_TRY(hipMemcpyAsync(h_dst, E.z_packed2[slot].p, f.exact, hipMemcpyDeviceToHost, E.stream_copy));
+	HIP_TRY(hipEventRecord(E.ev_copied[slot], E.stream_copy));
+	*done = E.ev_copied[slot];
+	(void)lk;
+	return CCT_OK;
+}
+
+// archive layout, any destination: exact pack on the device, one copy (through the pinned stage unless the destination is
+// page-locked itself, then a threaded memcpy)
+static int files_to_archive(FilesOut &f, uint8_t *h_dst, double *t_copied)
+{
+	EncSlot &E = f.E;
+	int rc;
+	const size_t cap = f.offs[f.nc] + 16;
+	if ((rc = E.z_packed.ensure(cap))) return rc;
+	HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, f.zstride, (const uint32_t *)E.z_outsizes.p, f.nc,
+	                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 1, E.stream));
+	if (is_pinned_host(h_dst, f.exact)) {
+		HIP_TRY(hipMemcpyAsync(h_dst, E.z_packed.p, f.exact, hipMemcpyDeviceToHost, E.stream));
+		HIP_TRY(hipStreamSynchronize(E.stream));
+		*t_copied = now_ms();
+		return CCT_OK;
+	}
+	if ((rc = E.h_stage.ensure(cap))) return rc;
+	HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, f.exact, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipStreamSynchronize(E.stream));
+	*t_copied = now_ms();
+	const int nt = std::min(g_ctx.zlib_threads, 16);
+	const size_t per = (f.exact + nt - 1) / nt;
+	const uint8_t *stg = (const uint8_t *)E.h_stage.p;
+	const size_t exact = f.exact;
+	parallel_for(nt, nt, [&](int t) {
+		const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
+		if (lo < hi) memcpy(h_dst + lo, stg + lo, hi - lo);
+	});
+	return CCT_OK;
+}
+
+// strided layout (file i at h_out + i * out_stride): 16-byte aligned pack on the device, one copy into the pinned stage,
+// threaded scatter
+static int files_to_strided(FilesOut &f, uint8_t *h_first, size_t out_stride)
+{
+	EncSlot &E = f.E;
+	int rc;
+	const size_t packed_cap = f.offs[f.nc];
+	if ((rc = E.z_packed.ensure(packed_cap + 16))) return rc;
+	if ((rc = E.h_stage.ensure(packed_cap + 16))) return rc;
+	HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, f.zstride, (const uint32_t *)E.z_outsizes.p, f.nc,
+	                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 0, E.stream));
+	HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, packed_cap, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipStreamSynchronize(E.stream));
+	const uint8_t *stg = (const uint8_t *)E.h_stage.p;
+	const uint32_t *osz = f.osz;
+	const std::vector<size_t> &offs = f.offs;
+	parallel_for(f.nc, std::min(g_ctx.zlib_threads, 32), [&](int i) { memcpy(h_first + (size_t)i * out_stride, stg + offs[i], osz[i]); });
+	return CCT_OK;
+}
+
+// DEFLATE (or none) on the host thread team: payloads come back, libz level 9 per slice (core.py:340), header in front
+static int files_on_host(EncSlot &E, int n, size_t stride, const std::vector<uint32_t> &psz, const uint8_t hdr13[13], bool defl,
+                         uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, const uint32_t *h_status)
+{
+	const double t_copy0 = now_ms();
+	uint8_t *stage = (uint8_t *)E.h_stage.p;
+	for (int i = 0; i < n; i++) {  // bring back only the bytes each slice produced
+		if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
+		HIP_TRY(hipMemcpyAsync(stage + (size_t)i * stride, (uint8_t *)E.e_payload.p + (size_t)i * stride, psz[i],
+		                       hipMemcpyDeviceToHost, E.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(E.stream));
+	const double t_defl0 = now_ms();
+	tl_d2h_ms = (float)(t_defl0 - t_copy0);
+	std::atomic<int> zerr(0);
+	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
+		uint8_t *o = h_out + (size_t)i * out_stride;
+		memcpy(o, hdr13, 13);
+		const uint8_t *pl = stage + (size_t)i * stride;
+		if (defl) {  // zlib.compress(data, level=9), core.py:340
+			uLongf dl = (uLongf)(out_stride - 13);
+			const int zr = compress2(o + 13, &dl, pl, psz[i], 9);
+			if (zr != Z_OK) { zerr.store(zr); h_out_sizes[i] = 0; return; }
+			h_out_sizes[i] = 13 + (uint32_t)dl;
+		} else {
+			memcpy(o + 13, pl, psz[i]);
+			h_out_sizes[i] = 13 + psz[i];
+		}
+	});
+	tl_deflate_ms = (float)(now_ms() - t_defl0);
+	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
+	return CCT_OK;
+}
+
 static int encode_batch_impl(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
                              uint32_t flags, int eof_byte, const char magic[4], int channels, int bytes_per_channel,
                              uint8_t *h_out, size_t out_stride, uint32_t *h_out_sizes, uint32_t *h_status,
@@ -986,19 +1140,8 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		std::lock_guard<std::mutex> lk0(g_mu);
 		if ((rc = ensure_ctx())) return rc;
 	}
-	// take a free encode slot (see EncSlot): the first caller gets slot 0, one that arrives while it is busy slot 1
-	std::mutex *const slot_mu[N_ENC_SLOTS] = {&g_mu, &g_mu1};
 	std::unique_lock<std::mutex> lk;
-	int slot = -1;
-	const int nslots = std::max(1, std::min(g_ctx.enc_slots, N_ENC_SLOTS));
-	while (slot < 0) {
-		for (int k = 0; k < nslots && slot < 0; k++) {
-			std::unique_lock<std::mutex> t(*slot_mu[k], std::try_to_lock);
-			if (t.owns_lock()) { lk = std::move(t); slot = k; }
-		}
-		if (slot < 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
-	}
-	EncSlot &E = g_enc[slot];
+	EncSlot &E = acquire_encode_slot(lk);
 	const double t_lock0 = now_ms();
 	if ((rc = ensure_ctx())) return rc;
 	if (n == 0) return CCT_OK;
@@ -1044,14 +1187,8 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		drain.disarm();
 		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, E.ev_k0, E.ev_k1));
 	}
-	uint8_t hdr13[13];  // core.py:193-210 (big-endian fields, values masked to a byte / 16 bits)
-	hdr13[0] = (uint8_t)magic[0]; hdr13[1] = (uint8_t)magic[1]; hdr13[2] = (uint8_t)magic[2]; hdr13[3] = (uint8_t)magic[3];
-	hdr13[4] = (uint8_t)((width >> 8) & 0xFF); hdr13[5] = (uint8_t)(width & 0xFF);
-	hdr13[6] = (uint8_t)((height >> 8) & 0xFF); hdr13[7] = (uint8_t)(height & 0xFF);
-	hdr13[8] = (uint8_t)(channels & 0xFF); hdr13[9] = (uint8_t)(bytes_per_channel & 0xFF);
-	hdr13[10] = (flags & CCT_FLAG_FRACTAL) ? 1 : 0;
-	hdr13[11] = (flags & CCT_FLAG_SEGMENTATION) ? 1 : 0;
-	hdr13[12] = defl ? 1 : 0;
+	uint8_t hdr13[13];
+	make_header13(hdr13, magic, width, height, channels, bytes_per_channel, flags);
 	if (defl && g_ctx.device_deflate) {
 		// DEFLATE on the device: zlib.compress(data, level=9) (core.py:340) restated in deflate_kernels.hip
 		if (!one_pass)
@@ -1080,123 +1217,45 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			}
 			tl_deflate_ms += E.t_dev_deflate_ms;
 			const double t_c0 = now_ms();
-			// pack the files back to back on the device, one copy into pinned memory, threaded scatter
-			std::vector<size_t> offs(nc + 1, 0);
-			for (int i = 0; i < nc; i++) offs[i + 1] = offs[i] + (((size_t)osz[i] + 15) & ~(size_t)15);
-			const size_t packed_cap = offs[nc];
-			if ((rc = E.z_packed.ensure(packed_cap + 16))) return rc;
+			FilesOut f{E, nc, osz, zstride, 0, std::vector<size_t>(nc + 1, 0)};
+			for (int i = 0; i < nc; i++) { f.exact += osz[i]; f.offs[i + 1] = f.offs[i] + (((size_t)osz[i] + 15) & ~(size_t)15); }
 			if ((rc = E.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
-			if ((rc = E.h_stage.ensure(packed_cap + 16))) return rc;
-			if (packed) {  // archive layout straight into the caller's buffer
-				size_t exact = 0;
-				for (int i = 0; i < nc; i++) exact += osz[i];
-				if (c0 == 0) h_packed_offsets[0] = 0;
-				const uint64_t at = h_packed_offsets[c0];
-				if (at + exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + exact));
-				if (nc == n && is_pinned_host(h_out + at, exact)) {
-					// whole batch in one pass into a page-locked archive: pack into one of two device buffers, hand the
-					// copy to the copy stream and give the device lock back before waiting for it
-					const unsigned slot = E.pack_slot++ & 1u;
-					if (!E.stream_copy) {
-						HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
-						for (int k = 0; k < 2; k++) {
-							HIP_TRY(hipEventCreateWithFlags(&E.ev_pack[k], hipEventDisableTiming));
-							HIP_TRY(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
-							HIP_TRY(hipEventRecord(E.ev_copied[k], E.stream_copy));
-						}
-					}
-					if (E.z_packed2[slot].cap < packed_cap + 16) HIP_TRY(hipEventSynchronize(E.ev_copied[slot]));  // about to be reallocated
-					if ((rc = E.z_packed2[slot].ensure(packed_cap + 16))) return rc;
-					HIP_TRY(hipStreamWaitEvent(E.stream, E.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
-					HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
-					                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed2[slot].p, 1, E.stream));
-					HIP_TRY(hipEventRecord(E.ev_pack[slot], E.stream));
-					HIP_TRY(hipStreamWaitEvent(E.stream_copy, E.ev_pack[slot], 0));
-					HIP_TRY(hipMemcpyAsync(h_out + at, E.z_packed2[slot].p, exact, hipMemcpyDeviceToHost, E.stream_copy));
-					HIP_TRY(hipEventRecord(E.ev_copied[slot], E.stream_copy));
-					hipEvent_t done = E.ev_copied[slot];
-					for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
-					if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
-					const float t_defl = E.t_dev_deflate_ms;
-					const double t_unlock = now_ms();
-					lk.unlock();
-					HIP_TRY(hipEventSynchronize(done));
-					const float t_tail = (float)(now_ms() - t_c0);
-					if (getenv("CCT_TRACE"))
-						fprintf(stderr, "[cct] encode n=%d: waited for the lock %.2f ms, held it %.2f ms (kernel %.2f, deflate %.2f), tail %.2f ms, t=%.2f\n", nc,
-						        t_lock0 - t_call0, t_unlock - t_lock0, tl_enc_kernel_ms, t_defl, now_ms() - t_unlock, t_lock0);
-					tl_d2h_ms = t_tail;  // (no lock: a float for cct_last_timings; re-locking would wait for the next batch)
-					return CCT_OK;
-				}
-				HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
-				                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 1, E.stream));
-				double t_c1;
-				if (is_pinned_host(h_out + at, exact)) {  // the caller's archive is page-locked: no staging pass
-					HIP_TRY(hipMemcpyAsync(h_out + at, E.z_packed.p, exact, hipMemcpyDeviceToHost, E.stream));
-					HIP_TRY(hipStreamSynchronize(E.stream));
-					t_c1 = now_ms();
-				} else {
-					HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, exact, hipMemcpyDeviceToHost, E.stream));
-					HIP_TRY(hipStreamSynchronize(E.stream));
-					t_c1 = now_ms();
-					const int nt = std::min(g_ctx.zlib_threads, 16);
-					const size_t per = (exact + nt - 1) / nt;
-					const uint8_t *stg = (const uint8_t *)E.h_stage.p;
-					parallel_for(nt, nt, [&](int t) {
-						const size_t lo = (size_t)t * per, hi = std::min(exact, lo + per);
-						if (lo < hi) memcpy(h_out + at + lo, stg + lo, hi - lo);
-					});
-				}
-				for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
+			if (!packed) {
+				if ((rc = files_to_strided(f, h_out + (size_t)c0 * out_stride, out_stride))) return rc;
 				tl_d2h_ms += (float)(now_ms() - t_c0);
-				if (getenv("CCT_TRACE"))
-					fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
-					        E.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, exact);
 				continue;
 			}
-			HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
-			                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed.p, 0, E.stream));
-			HIP_TRY(hipMemcpyAsync(E.h_stage.p, E.z_packed.p, packed_cap, hipMemcpyDeviceToHost, E.stream));
-			HIP_TRY(hipStreamSynchronize(E.stream));
-			const uint8_t *stg = (const uint8_t *)E.h_stage.p;
-			parallel_for(nc, std::min(g_ctx.zlib_threads, 32),
-			             [&](int i) { memcpy(h_out + (size_t)(c0 + i) * out_stride, stg + offs[i], osz[i]); });
+			if (c0 == 0) h_packed_offsets[0] = 0;
+			const uint64_t at = h_packed_offsets[c0];
+			if (at + f.exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + f.exact));
+			for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
+			if (nc == n && is_pinned_host(h_out + at, f.exact)) {
+				hipEvent_t done = nullptr;
+				if ((rc = files_to_pinned_archive_async(f, h_out + at, lk, &done))) return rc;
+				if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
+				const float t_defl = E.t_dev_deflate_ms;
+				const double t_unlock = now_ms();
+				lk.unlock();  // the slot is free for the next batch; only the copy stream still works for this one
+				HIP_TRY(hipEventSynchronize(done));
+				if (getenv("CCT_TRACE"))
+					fprintf(stderr, "[cct] encode n=%d: waited for a slot %.2f ms, held it %.2f ms (kernel %.2f, deflate %.2f), tail %.2f ms, t=%.2f\n", nc,
+					        t_lock0 - t_call0, t_unlock - t_lock0, tl_enc_kernel_ms, t_defl, now_ms() - t_unlock, t_lock0);
+				tl_d2h_ms = (float)(now_ms() - t_c0);  // (no lock: a float for cct_last_timings)
+				return CCT_OK;
+			}
+			double t_c1 = t_c0;
+			if ((rc = files_to_archive(f, h_out + at, &t_c1))) return rc;
 			tl_d2h_ms += (float)(now_ms() - t_c0);
+			if (getenv("CCT_TRACE"))
+				fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
+				        E.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, f.exact);
 		}
 		if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 		return CCT_OK;
 	}
-	const double t_copy0 = now_ms();
-	// bring back only the bytes each slice produced
-	uint8_t *stage = (uint8_t *)E.h_stage.p;
-	for (int i = 0; i < n; i++) {
-		if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
-		HIP_TRY(hipMemcpyAsync(stage + (size_t)i * stride, (uint8_t *)E.e_payload.p + (size_t)i * stride, psz[i],
-		                       hipMemcpyDeviceToHost, E.stream));
-	}
-	HIP_TRY(hipStreamSynchronize(E.stream));
-	const double t_defl0 = now_ms();
-	tl_d2h_ms = (float)(t_defl0 - t_copy0);
-
-	std::atomic<int> zerr(0);
-	parallel_for(n, defl ? g_ctx.zlib_threads : 1, [&](int i) {
-		uint8_t *o = h_out + (size_t)i * out_stride;
-		memcpy(o, hdr13, 13);
-		const uint8_t *pl = stage + (size_t)i * stride;
-		if (defl) {  // zlib.compress(data, level=9), core.py:340
-			uLongf dl = (uLongf)(out_stride - 13);
-			const int zr = compress2(o + 13, &dl, pl, psz[i], 9);
-			if (zr != Z_OK) { zerr.store(zr); h_out_sizes[i] = 0; return; }
-			h_out_sizes[i] = 13 + (uint32_t)dl;
-		} else {
-			memcpy(o + 13, pl, psz[i]);
-			h_out_sizes[i] = 13 + psz[i];
-		}
-	});
-	tl_deflate_ms = (float)(now_ms() - t_defl0);
+	rc = files_on_host(E, n, stride, psz, hdr13, defl, h_out, out_stride, h_out_sizes, h_status);
 	if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
-	if (zerr.load()) return fail(CCT_E_ZLIB, "compress2 failed (%d)", zerr.load());
-	return CCT_OK;
+	return rc;
 }
 
 int cct_encode_batch(const uint16_t *images, int images_on_device, int n, int width, int height, int block_size,
