@@ -416,6 +416,9 @@ def main():
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)",
                        "encode_slots": args.encode_slots},
             "roofline": main_roof,
+            "hbm_read_roofline_end_to_end": {  # north_star: the whole job against the HBM-read roofline (2 B per pixel per step)
+                "achieved": round(2.0 * npx * world / (ms_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": round(2.0 * npx / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "rooflines": others if decode_only else dict(others, transform_pack=pack),
             "stages": {
                 "encode_transform_pack_MPix_s": round(npx / (enc_kernel_ms * 1e-3) / 1e6, 1),

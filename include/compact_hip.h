@@ -12,13 +12,17 @@
  * Conventions: plain pointers and sizes only; every function returns 0 on success or a
  * CCT_E_* code and never throws; buffers are caller-allocated; "d_" pointers are device
  * (HBM) addresses obtained from cct_dev_alloc (or any hipMalloc), "h_" pointers are host
- * addresses.  Encode-side launches go to one internal HIP stream per process and are
- * serialised by an internal mutex; decode calls (cct_decode_batch, cct_zlib_decompress_batch)
- * run on a second stream of their own so that one decode may overlap one encode.  The two
- * streams are NOT ordered against each other: every host-facing call is complete when it
- * returns (cct_dev_memset and the h2d/d2h copies included); only cct_encode_payload_dev /
- * cct_decode_payload_dev leave work queued -- call cct_sync() before another call reads
- * or overwrites their buffers.
+ * addresses.  Threading: calls may come from several host threads.  An encode batch call
+ * (cct_encode_batch, cct_encode_batch_packed) takes one of two internal encode slots -- a
+ * HIP stream with its own workspaces -- so two of them run side by side on the device and a
+ * third waits (option "encode_slots" = 1: one at a time); decode calls (cct_decode_batch,
+ * cct_zlib_decompress_batch) run on a stream of their own, one at a time, next to the
+ * encodes; the size gather (cct_allgather_u32) has its own stream as well.  Everything else
+ * shares the main stream (= encode slot 0) under one mutex.  The streams are NOT ordered
+ * against each other: every host-facing call is complete when it returns (cct_dev_memset
+ * and the h2d/d2h copies included); only cct_encode_payload_dev / cct_decode_payload_dev
+ * leave work queued (main / decode stream) -- call cct_sync() before another call reads or
+ * overwrites their buffers.
  * The library initialises HIP lazily on the first device call.  Processes that fork
  * workers (scripts/evaluate.py:107) must fork BEFORE that call: each child then binds the
  * GPU itself.  A child forked after its parent initialised the GPU gets CCT_E_DEVICE from
