@@ -1094,31 +1094,90 @@ __device__ void tree_codes(TreeScratch &S, int kind)
 	}
 }
 
-__device__ void scan_tree(TreeScratch &S, const TreeView &t, int max_code)
+// scan_tree + the token side of send_tree (trees.c:703-800), by the whole wave.  trees.c walks the code lengths with a
+// small state machine (count, max_count, min_count, prevlen); its state is reset at every change of value, so what it emits
+// for a maximal run of R equal lengths v depends on (v, R) only:
+//   v != 0:  R < 4: v, R times.   4 <= R <= 6: v, then REP_3_6(R - 1).   R >= 7: v, REP_3_6(6), then REP_3_6(6) for every
+//            further six, and for the r = (R - 7) % 6 left over r times v (r < 3) or REP_3_6(r)
+//   v == 0:  REPZ_11_138(138) for every 138, and for the r = R % 138 left over r times 0 (r < 3), REPZ_3_10(r) (r <= 10) or
+//            REPZ_11_138(r)
+// (the first chunk of a non-zero run is cut at 7 = literal + repeat of 6, later ones at 6; zero runs at 138).  So every run
+// start computes its tokens on its own; a prefix sum over the runs gives the place in the token list.
+// token = symbol 0..18 | extra-bits value << 5; bit-length frequencies are counted in S.hdr_bits[0..18] (free until the
+// header is written) and moved to bfreq by the caller.
+__device__ void scan_tree_wave(TreeScratch &S, const TreeView &t, int max_code)
 {
-	int n, prevlen = -1, curlen, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
-	if (nextlen == 0) { max_count = 138; min_count = 3; }
-	t.len[max_code + 1] = 0xffff;
-	// the tokens send_tree (trees.c:757-800) would write for this sequence are recorded on the way: the same walk, once
-	uint16_t *tk = S.tok();
-	int nt = S.ntok;
-	for (n = 0; n <= max_code; n++) {
-		curlen = nextlen; nextlen = t.len[n + 1];
-		if (++count < max_count && curlen == nextlen) continue;
-		else if (count < min_count) {
-			S.bfreq[curlen] += (uint16_t)count;
-			for (int c = 0; c < count; c++) tk[nt++] = (uint16_t)curlen;
-		} else if (curlen != 0) {
-			if (curlen != prevlen) { S.bfreq[curlen]++; tk[nt++] = (uint16_t)curlen; count--; }
-			S.bfreq[16]++; tk[nt++] = (uint16_t)(16 | ((count - 3) << 5));
-		} else if (count <= 10) { S.bfreq[17]++; tk[nt++] = (uint16_t)(17 | ((count - 3) << 5)); }
-		else { S.bfreq[18]++; tk[nt++] = (uint16_t)(18 | ((count - 11) << 5)); }
-		count = 0; prevlen = curlen;
-		if (nextlen == 0) { max_count = 138; min_count = 3; }
-		else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-		else { max_count = 7; min_count = 4; }
+	const int lane = threadIdx.x;
+	constexpr int NCH = (L_CODES + 63) / 64;  // 5 chunks of 64 positions
+	const int n_el = max_code + 1;
+	uint32_t v[NCH];
+	uint64_t startmask[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+		const int n = c * 64 + lane;
+		v[c] = n < n_el ? (uint32_t)t.len[n] : 0xFFFFu;
+		const uint32_t before = n == 0 ? 0xFFFFFFFFu : (uint32_t)t.len[max(n - 1, 0)];
+		startmask[c] = __ballot(n < n_el && v[c] != before);
 	}
-	S.ntok = nt;
+	uint16_t *tk = S.tok();
+	uint32_t base = (uint32_t)S.ntok;
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+		if (c * 64 >= n_el) break;  // (uniform)
+		const int n = c * 64 + lane;
+		const bool start = (startmask[c] >> lane) & 1ull;
+		// run length: distance to the next run start (or to the end of the sequence)
+		uint32_t R = 0;
+		if (start) {
+			int nxt = n_el;
+			const uint64_t rest = lane < 63 ? startmask[c] >> (lane + 1) : 0ull;
+			if (rest) nxt = n + (int)__ffsll((long long)rest);
+			else {
+#pragma unroll
+				for (int c2 = NCH - 1; c2 > c; c2--) if (startmask[c2]) nxt = min(nxt, c2 * 64 + (int)__ffsll((long long)startmask[c2]) - 1);
+				// (descending loop with min: the nearest following chunk that has a start wins)
+			}
+			R = (uint32_t)(nxt - n);
+		}
+		const uint32_t val = v[c];
+		// tokens of the run
+		uint32_t nlit_head = 0, nrep6 = 0, tail_lit = 0, tail_sym = 0xFFFFFFFFu, nbig = 0;
+		if (start) {
+			if (val != 0) {
+				if (R < 4) nlit_head = R;
+				else if (R <= 6) { nlit_head = 1; tail_sym = 16u | ((R - 4u) << 5); }
+				else {
+					nlit_head = 1; nrep6 = 1 + (R - 7u) / 6u;
+					const uint32_t r = (R - 7u) % 6u;
+					if (r < 3) tail_lit = r; else tail_sym = 16u | ((r - 3u) << 5);
+				}
+			} else {
+				nbig = R / 138u;
+				const uint32_t r = R % 138u;
+				if (r < 3) tail_lit = r;
+				else if (r <= 10) tail_sym = 17u | ((r - 3u) << 5);
+				else tail_sym = 18u | ((r - 11u) << 5);
+			}
+		}
+		const uint32_t ntok = nlit_head + nrep6 + nbig + tail_lit + (tail_sym != 0xFFFFFFFFu ? 1u : 0u);
+		uint32_t inc = ntok;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+		if (start) {
+			uint32_t w = base + inc - ntok;
+			for (uint32_t i = 0; i < nlit_head; i++) tk[w++] = (uint16_t)val;
+			for (uint32_t i = 0; i < nrep6; i++) tk[w++] = (uint16_t)(16u | (3u << 5));
+			for (uint32_t i = 0; i < nbig; i++) tk[w++] = (uint16_t)(18u | (127u << 5));
+			for (uint32_t i = 0; i < tail_lit; i++) tk[w++] = (uint16_t)val;
+			if (tail_sym != 0xFFFFFFFFu) tk[w++] = (uint16_t)tail_sym;
+			if (nlit_head + tail_lit) atomicAdd(&S.hdr_bits[val], nlit_head + tail_lit);
+			if (nrep6) atomicAdd(&S.hdr_bits[16], nrep6);
+			if (nbig) atomicAdd(&S.hdr_bits[18], nbig);
+			if (tail_sym != 0xFFFFFFFFu) atomicAdd(&S.hdr_bits[tail_sym & 31u], 1u);
+		}
+		base += (uint32_t)__shfl((int)inc, 63, 64);
+	}
+	if (lane == 0) S.ntok = (int)base;
 }
 
 // `n` bits of `value` at bit position `pos` of the (zeroed) header image
@@ -1209,12 +1268,12 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		for (int i = lane; i < L_CODES; i += 64) hl[i] = 0;
 		if (lane < D_CODES) hd[lane] = 0;
 		__syncthreads();
-		for (uint32_t i0 = 0; i0 < nsym; i0 += 64 * 8) {  // eight loads in flight: one wave per block, nothing else hides HBM latency
-			uint32_t v[8];
+		for (uint32_t i0 = 0; i0 < nsym; i0 += 64 * 16) {  // sixteen loads in flight: one wave per block, nothing else hides HBM latency
+			uint32_t v[16];
 #pragma unroll
-			for (int k = 0; k < 8; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < nsym ? sym[i] : 0xFFFFFFFFu; }
+			for (int k = 0; k < 16; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < nsym ? sym[i] : 0xFFFFFFFFu; }
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
+			for (int k = 0; k < 16; k++) {
 				if (v[k] == 0xFFFFFFFFu) continue;  // (a symbol never looks like this: length codes are <= 255)
 				const uint32_t dist = v[k] >> 16, lc = v[k] & 0xFFu;
 				if (dist == 0) atomicAdd(&hl[lc], 1u);
@@ -1239,11 +1298,15 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 #pragma unroll 1
 	for (int kind = 0; kind < 3; kind++) {  // literal/length, distance, then the bit-length tree over both
 		if (kind == 2) {
-			if (owner) {
-				TreeScratch &S = S4[lane];
-				S.dyn_body_bits = S.opt_len;  // code + extra bits of all symbols and END_BLOCK
-#pragma unroll 1
-				for (int w = 0; w < 2; w++) scan_tree(S, view_of(S, w), w ? S.dmax : S.lmax);
+			if (owner) S4[lane].dyn_body_bits = S4[lane].opt_len;  // code + extra bits of all symbols and END_BLOCK
+			__syncthreads();
+			for (int q = 0; q < nb; q++) {
+				TreeScratch &S = S4[q];
+				scan_tree_wave(S, view_of(S, 0), S.lmax);
+				__syncthreads();  // (the token count of the first sequence is the base of the second)
+				scan_tree_wave(S, view_of(S, 1), S.dmax);
+				__syncthreads();
+				if (lane < BL_CODES) { S.bfreq[lane] = (uint16_t)S.hdr_bits[lane]; S.hdr_bits[lane] = 0; }
 			}
 			__syncthreads();
 		}
