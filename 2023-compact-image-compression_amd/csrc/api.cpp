@@ -107,6 +107,30 @@ struct EncSlot {
 };
 constexpr int N_ENC_SLOTS = 2;
 
+// The same for a decode batch in flight (cct_decode_batch, cct_zlib_decompress_batch): stream, workspaces, events.  With two of
+// them the archive upload of one batch runs under the INFLATE and decode kernels of the other (what bounds a decode-only
+// caller: BASELINE configs[4]).
+struct DecSlot {
+	std::mutex mu;
+	hipStream_t stream = nullptr;  // slot 0: Context::stream_dec
+	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
+	DevBuf d_arch, d_archoffs, d_zstatus;
+	DevBuf dh_stage;  // pinned host staging of inflated payloads (host INFLATE path)
+	hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
+	DevBuf *all_bufs[16];
+	int n_bufs = 0;
+	DecSlot()
+	{
+		DevBuf *b[] = {&d_role, &d_slot, &d_jord, &d_jval, &d_payload, &d_sizes, &d_status, &d_images, &d_pcache, &d_arch, &d_archoffs,
+		               &d_zstatus, &dh_stage};
+		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
+		dh_stage.pinned_host = true;
+	}
+	DecSlot(const DecSlot &) = delete;
+	DecSlot &operator=(const DecSlot &) = delete;
+};
+constexpr int N_DEC_SLOTS = 2;
+
 struct Context {
 	bool ready = false;
 	pid_t pid = 0;
@@ -122,17 +146,12 @@ struct Context {
 	float pipe_us[4] = {0, 0, 0, 0};
 	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel)
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
-	// decode workspaces
-	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
 	int device_inflate = 1;  // option "device_inflate": 1 = INFLATE on the device (inflate_kernels.hip, speculative lane-parallel
 	                         // decode), 0 = libz on the host thread team (same bytes; bounded by the host CPUs the process may use)
-	DevBuf d_arch, d_archoffs, d_zstatus;
 	int zlib_threads = 0;
 	int wg_threads = 1024;
-	// timings of the most recent batch call (cct_last_timings)
-	hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
-	DevBuf dh_stage;  // pinned host staging of inflated payloads (decode owns it, see g_mu_dec)
+	int dec_slots = N_DEC_SLOTS;  // option "decode_slots"
 };
 
 double now_ms()
@@ -143,14 +162,18 @@ double now_ms()
 
 Context g_ctx;
 EncSlot *g_enc = new EncSlot[N_ENC_SLOTS];
-void reset_ctx() { g_ctx = Context(); delete[] g_enc; g_enc = new EncSlot[N_ENC_SLOTS]; }
+DecSlot *g_dec = new DecSlot[N_DEC_SLOTS];
+void reset_ctx()
+{
+	g_ctx = Context();
+	delete[] g_enc; g_enc = new EncSlot[N_ENC_SLOTS];
+	delete[] g_dec; g_dec = new DecSlot[N_DEC_SLOTS];
+}
 // timings of the calling thread's most recent batch call (cct_last_timings): per thread, so that an encode and a
 // decode driven from two threads do not overwrite each other's numbers
 thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
 std::mutex g_mu1;     // encode slot 1
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
-std::mutex g_mu_dec;  // one cct_decode_batch at a time; its host INFLATE phase runs outside g_mu so that
-                      // another thread's encode (device DEFLATE) can overlap with it
 
 int default_device()
 {
@@ -208,11 +231,15 @@ int ensure_ctx(int device)
 		HIP_TRY(hipEventCreate(&E.ev_z0));
 		HIP_TRY(hipEventCreate(&E.ev_z1));
 	}
-	HIP_TRY(hipEventCreate(&g_ctx.ev_d0));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_d1));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec0));
-	HIP_TRY(hipEventCreate(&g_ctx.ev_k_dec1));
-	g_ctx.dh_stage.pinned_host = true;
+	for (int k = 0; k < N_DEC_SLOTS; k++) {
+		DecSlot &D = g_dec[k];
+		if (k == 0) D.stream = g_ctx.stream_dec;
+		else HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreate(&D.ev_d0));
+		HIP_TRY(hipEventCreate(&D.ev_d1));
+		HIP_TRY(hipEventCreate(&D.ev_k_dec0));
+		HIP_TRY(hipEventCreate(&D.ev_k_dec1));
+	}
 	HIP_TRY(deflate_init_tables());  // __constant__ tables of the DEFLATE kernels, shared by both encode slots
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
@@ -714,7 +741,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	return CCT_OK;
 }
 
-int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_t *d_sizes, int n, int width,
+int decode_payload_locked(DecSlot &D, const uint8_t *d_payload, size_t stride, const uint32_t *d_sizes, int n, int width,
                           int height, int bs, int fractal, uint16_t *d_images, uint32_t *d_status, hipStream_t st)
 {
 	const int N = width * height, NB = N / bs;
@@ -737,15 +764,15 @@ int decode_payload_locked(const uint8_t *d_payload, size_t stride, const uint32_
 	a.N = N; a.NB = NB; a.images = d_images; a.status = d_status;
 	const size_t per = (size_t)n * NB, jper = (size_t)n * ((size_t)NB / 2 + 1);
 	int rc;
-	if ((rc = g_ctx.d_role.ensure(per))) return rc;
-	if ((rc = g_ctx.d_slot.ensure(per * 4))) return rc;
-	if ((rc = g_ctx.d_jord.ensure(jper * 4))) return rc;
-	if ((rc = g_ctx.d_jval.ensure(jper))) return rc;
-	a.ws_role = (uint8_t *)g_ctx.d_role.p; a.ws_slot = (uint32_t *)g_ctx.d_slot.p;
-	a.ws_jord = (uint32_t *)g_ctx.d_jord.p; a.ws_jval = (uint8_t *)g_ctx.d_jval.p;
+	if ((rc = D.d_role.ensure(per))) return rc;
+	if ((rc = D.d_slot.ensure(per * 4))) return rc;
+	if ((rc = D.d_jord.ensure(jper * 4))) return rc;
+	if ((rc = D.d_jval.ensure(jper))) return rc;
+	a.ws_role = (uint8_t *)D.d_role.p; a.ws_slot = (uint32_t *)D.d_slot.p;
+	a.ws_jord = (uint32_t *)D.d_jord.p; a.ws_jval = (uint8_t *)D.d_jval.p;
 	a.pcache_steps = (int)(stride / ((size_t)g_ctx.wg_threads * DEC_SEG) + 2);
-	if ((rc = g_ctx.d_pcache.ensure((size_t)n * a.pcache_steps * g_ctx.wg_threads * sizeof(uint2)))) return rc;
-	a.ws_pcache = (uint2 *)g_ctx.d_pcache.p;
+	if ((rc = D.d_pcache.ensure((size_t)n * a.pcache_steps * g_ctx.wg_threads * sizeof(uint2)))) return rc;
+	a.ws_pcache = (uint2 *)D.d_pcache.p;
 	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, st));
 	return CCT_OK;
 }
@@ -770,7 +797,8 @@ int cct_shutdown(void)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	std::lock_guard<std::mutex> lk1(g_mu1);
-	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	std::lock_guard<std::mutex> lkd0(g_dec[0].mu);
+	std::lock_guard<std::mutex> lkd1(g_dec[1].mu);
 	if (!g_ctx.ready || g_ctx.pid != getpid()) { reset_ctx(); return CCT_OK; }
 	(void)hipSetDevice(g_ctx.device);
 	(void)hipStreamSynchronize(g_ctx.stream);
@@ -794,11 +822,14 @@ int cct_shutdown(void)
 		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
 		for (void *p : ptrs) if (p) (void)hipFree(p);
 	}
-	DevBuf *bufs[] = {&g_ctx.d_role, &g_ctx.d_slot, &g_ctx.d_jord, &g_ctx.d_jval, &g_ctx.d_payload, &g_ctx.d_sizes, &g_ctx.d_status,
-	                  &g_ctx.d_images, &g_ctx.d_pcache, &g_ctx.d_arch, &g_ctx.d_archoffs, &g_ctx.d_zstatus, &g_ctx.dh_stage};
-	for (DevBuf *b : bufs) b->release();
-	hipEvent_t evs[] = {g_ctx.ev_d0, g_ctx.ev_d1, g_ctx.ev_k_dec0, g_ctx.ev_k_dec1};
-	for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+	for (int k = 0; k < N_DEC_SLOTS; k++) {
+		DecSlot &D = g_dec[k];
+		if (D.stream) (void)hipStreamSynchronize(D.stream);
+		for (int i = 0; i < D.n_bufs; i++) D.all_bufs[i]->release();
+		hipEvent_t evs[] = {D.ev_d0, D.ev_d1, D.ev_k_dec0, D.ev_k_dec1};
+		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+		if (k > 0 && D.stream) (void)hipStreamDestroy(D.stream);
+	}
 	(void)hipStreamDestroy(g_ctx.stream);
 	(void)hipStreamDestroy(g_ctx.stream_dec);
 	reset_ctx();
@@ -1317,10 +1348,24 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
 	return CCT_OK;
 }
 
+// take a free decode slot (see DecSlot)
+static DecSlot &acquire_decode_slot(std::unique_lock<std::mutex> &lk)
+{
+	const int nslots = std::max(1, std::min(g_ctx.dec_slots, N_DEC_SLOTS));
+	for (;;) {
+		for (int k = 0; k < nslots; k++) {
+			std::unique_lock<std::mutex> t(g_dec[k].mu, std::try_to_lock);
+			if (t.owns_lock()) { lk = std::move(t); return g_dec[k]; }
+		}
+		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	}
+}
+
 int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, uint8_t *h_out, size_t out_stride,
                               uint32_t *h_out_sizes, uint32_t *h_status)
 {
-	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	std::unique_lock<std::mutex> lkd;
+	DecSlot &D = acquire_decode_slot(lkd);
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (out_stride == 0 || (out_stride & 15)) return fail(CCT_E_ARG, "out_stride must be a positive multiple of 16");
 	if (!(g_ctx.ready && g_ctx.pid == getpid())) {
@@ -1333,34 +1378,34 @@ int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
 	HIP_TRY(hipSetDevice(g_ctx.device));
 	const uint64_t a0 = h_offsets[0], a1 = h_offsets[n];
 	const size_t abytes = (size_t)(a1 - a0), apad = (abytes + 31) & ~(size_t)15;
-	if ((rc = g_ctx.d_arch.ensure(apad + 16))) return rc;
-	if ((rc = g_ctx.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
-	if ((rc = g_ctx.d_zstatus.ensure((size_t)n * 4))) return rc;
-	if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
-	if ((rc = g_ctx.d_payload.ensure((size_t)n * out_stride))) return rc;
+	if ((rc = D.d_arch.ensure(apad + 16))) return rc;
+	if ((rc = D.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
+	if ((rc = D.d_zstatus.ensure((size_t)n * 4))) return rc;
+	if ((rc = D.d_sizes.ensure((size_t)n * 4))) return rc;
+	if ((rc = D.d_payload.ensure((size_t)n * out_stride))) return rc;
 	std::vector<uint64_t> rel(n + 1);
 	std::vector<uint32_t> zst(n), osz(n);
 	for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
-	hipStream_t st = g_ctx.stream_dec;
+	hipStream_t st = D.stream;
 	DrainOnExit drain(st);
-	HIP_TRY(hipMemsetAsync((uint8_t *)g_ctx.d_arch.p + (apad > 32 ? apad - 32 : 0), 0, apad > 32 ? 48 : apad + 16, st));
-	if (abytes) HIP_TRY(hipMemcpyAsync(g_ctx.d_arch.p, h_in + a0, abytes, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(g_ctx.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync((uint8_t *)D.d_arch.p + (apad > 32 ? apad - 32 : 0), 0, apad > 32 ? 48 : apad + 16, st));
+	if (abytes) HIP_TRY(hipMemcpyAsync(D.d_arch.p, h_in + a0, abytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(D.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 	InflateArgs ia{};
-	ia.in = (const uint8_t *)g_ctx.d_arch.p; ia.in_total = apad;
-	ia.offsets = (const uint64_t *)g_ctx.d_archoffs.p; ia.skip = 0;
-	ia.out = (uint8_t *)g_ctx.d_payload.p; ia.out_stride = out_stride;
-	ia.out_sizes = (uint32_t *)g_ctx.d_sizes.p; ia.status = (uint32_t *)g_ctx.d_zstatus.p;
+	ia.in = (const uint8_t *)D.d_arch.p; ia.in_total = apad;
+	ia.offsets = (const uint64_t *)D.d_archoffs.p; ia.skip = 0;
+	ia.out = (uint8_t *)D.d_payload.p; ia.out_stride = out_stride;
+	ia.out_sizes = (uint32_t *)D.d_sizes.p; ia.status = (uint32_t *)D.d_zstatus.p;
 	HIP_TRY(launch_inflate(ia, n, st));
-	HIP_TRY(hipMemcpyAsync(zst.data(), g_ctx.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(osz.data(), g_ctx.d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(zst.data(), D.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(osz.data(), D.d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	int first = CCT_OK;
 	for (int i = 0; i < n; i++) {
 		h_status[i] = (zst[i] & CCT_ST_ZLIB) ? CCT_E_ZLIB : (zst[i] & CCT_ST_STREAM) ? CCT_E_CAP : CCT_OK;
 		h_out_sizes[i] = h_status[i] == CCT_OK ? osz[i] : 0;
 		if (h_status[i] == CCT_OK && osz[i])
-			HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)g_ctx.d_payload.p + (size_t)i * out_stride, osz[i],
+			HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * out_stride, (uint8_t *)D.d_payload.p + (size_t)i * out_stride, osz[i],
 			                       hipMemcpyDeviceToHost, st));
 		if (h_status[i] != CCT_OK && first == CCT_OK) {
 			first = (int)h_status[i];
@@ -1389,19 +1434,20 @@ int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_
 int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, const uint32_t *d_payload_sizes, int n,
                            int width, int height, int block_size, int fractal, uint16_t *d_images, uint32_t *d_status)
 {
-	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	std::lock_guard<std::mutex> lkd(g_dec[0].mu);  // the workspaces of decode slot 0, on the main stream
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
-	return decode_payload_locked(d_payload, payload_stride, d_payload_sizes, n, width, height, block_size, fractal,
+	return decode_payload_locked(g_dec[0], d_payload, payload_stride, d_payload_sizes, n, width, height, block_size, fractal,
 	                             d_images, d_status, g_ctx.stream);
 }
 
 int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, int block_size, const char magic[4],
                      uint16_t *images, int images_on_device, size_t images_cap_px, uint32_t *h_status)
 {
-	std::lock_guard<std::mutex> lkd(g_mu_dec);
+	std::unique_lock<std::mutex> lkd;
+	DecSlot &D = acquire_decode_slot(lkd);
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (n == 0) return CCT_OK;
 	cct_header h0;
@@ -1423,61 +1469,63 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		std::lock_guard<std::mutex> lk(g_mu);
 		if ((rc = ensure_ctx())) return rc;
 	}
-	{  // decode-owned buffers (guarded by g_mu_dec); no device lock, an encode may be in flight
+	{  // the slot's own buffers; no device lock, encodes and the other decode slot may be in flight
 		HIP_TRY(hipSetDevice(g_ctx.device));
-		if ((rc = g_ctx.dh_stage.ensure((size_t)n * stride))) return rc;
-		if ((rc = g_ctx.d_payload.ensure((size_t)n * stride))) return rc;
-		if ((rc = g_ctx.d_sizes.ensure((size_t)n * 4))) return rc;
-		if ((rc = g_ctx.d_status.ensure((size_t)n * 4))) return rc;
-		if (!images_on_device && (rc = g_ctx.d_images.ensure((size_t)n * N * 2))) return rc;
+		if ((rc = D.dh_stage.ensure((size_t)n * stride))) return rc;
+		if ((rc = D.d_payload.ensure((size_t)n * stride))) return rc;
+		if ((rc = D.d_sizes.ensure((size_t)n * 4))) return rc;
+		if ((rc = D.d_status.ensure((size_t)n * 4))) return rc;
+		if (!images_on_device && (rc = D.d_images.ensure((size_t)n * N * 2))) return rc;
 		zthreads = g_ctx.zlib_threads;
 	}
-	uint8_t *stage = (uint8_t *)g_ctx.dh_stage.p;
+	uint8_t *stage = (uint8_t *)D.dh_stage.p;
 	std::vector<uint32_t> psz(n);
 	for (int i = 0; i < n; i++) h_status[i] = CCT_OK;
 	const bool dev_inflate = h0.deflate && g_ctx.device_inflate;
 	std::vector<uint32_t> dst(n), zst(n, 0);
 	std::vector<uint64_t> rel(dev_inflate ? n + 1 : 0);
-	DrainOnExit drain(g_ctx.stream_dec);  // copies into the vectors above / the caller's images must land before any return
+	DrainOnExit drain(D.stream);  // copies into the vectors above / the caller's images must land before any return
 	if (dev_inflate) {
 		// INFLATE on the device (inflate_kernels.hip): the archive goes up as it is, payloads never touch the host
 		const uint64_t a0 = h_offsets[0], a1 = h_offsets[n];
 		const size_t abytes = (size_t)(a1 - a0), apad = (abytes + 31) & ~(size_t)15;
 		HIP_TRY(hipSetDevice(g_ctx.device));
-		if ((rc = g_ctx.d_arch.ensure(apad + 16))) return rc;
-		if ((rc = g_ctx.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
-		if ((rc = g_ctx.d_zstatus.ensure((size_t)n * 4))) return rc;
+		if ((rc = D.d_arch.ensure(apad + 16))) return rc;
+		if ((rc = D.d_archoffs.ensure((size_t)(n + 1) * 8))) return rc;
+		if ((rc = D.d_zstatus.ensure((size_t)n * 4))) return rc;
 		for (int i = 0; i <= n; i++) rel[i] = h_offsets[i] - a0;
-		hipStream_t st = g_ctx.stream_dec;
+		hipStream_t st = D.stream;
 		const double t_inf0 = now_ms();
-		HIP_TRY(hipMemcpyAsync(g_ctx.d_arch.p, h_files + a0, abytes, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(g_ctx.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(D.d_arch.p, h_files + a0, abytes, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(D.d_archoffs.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
 		InflateArgs ia{};
-		ia.in = (const uint8_t *)g_ctx.d_arch.p; ia.in_total = apad;
-		ia.offsets = (const uint64_t *)g_ctx.d_archoffs.p; ia.skip = 13;
-		ia.out = (uint8_t *)g_ctx.d_payload.p; ia.out_stride = stride;
-		ia.out_sizes = (uint32_t *)g_ctx.d_sizes.p; ia.status = (uint32_t *)g_ctx.d_zstatus.p;
-		HIP_TRY(hipEventRecord(g_ctx.ev_d0, st));
+		ia.in = (const uint8_t *)D.d_arch.p; ia.in_total = apad;
+		ia.offsets = (const uint64_t *)D.d_archoffs.p; ia.skip = 13;
+		ia.out = (uint8_t *)D.d_payload.p; ia.out_stride = stride;
+		ia.out_sizes = (uint32_t *)D.d_sizes.p; ia.status = (uint32_t *)D.d_zstatus.p;
+		HIP_TRY(hipEventRecord(D.ev_d0, st));
 		HIP_TRY(launch_inflate(ia, n, st));
-		HIP_TRY(hipEventRecord(g_ctx.ev_d1, st));
-		uint16_t *d_img = images_on_device ? images : (uint16_t *)g_ctx.d_images.p;
-		hipEvent_t ev_k = g_ctx.ev_k_dec0, ev_k1 = g_ctx.ev_k_dec1;
+		HIP_TRY(hipEventRecord(D.ev_d1, st));
+		uint16_t *d_img = images_on_device ? images : (uint16_t *)D.d_images.p;
+		hipEvent_t ev_k = D.ev_k_dec0, ev_k1 = D.ev_k_dec1;
 		HIP_TRY(hipEventRecord(ev_k, st));
-		rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
-		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p, st);
+		rc = decode_payload_locked(D, (const uint8_t *)D.d_payload.p, stride, (const uint32_t *)D.d_sizes.p, n, h0.width,
+		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)D.d_status.p, st);
 		if (rc) return rc;
 		HIP_TRY(hipEventRecord(ev_k1, st));
-		HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipMemcpyAsync(zst.data(), g_ctx.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(dst.data(), D.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(zst.data(), D.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 		if (!images_on_device)
 			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipEventElapsedTime(&tl_inflate_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		HIP_TRY(hipEventElapsedTime(&tl_inflate_ms, D.ev_d0, D.ev_d1));
 		HIP_TRY(hipEventElapsedTime(&tl_dec_kernel_ms, ev_k, ev_k1));
 		(void)t_inf0;
 	} else {
 	// INFLATE stage: zlib.decompress(file_bytes[13:]), core.py:421 -- host threads, no device lock held
 	const double t_inf0 = now_ms();
+	static std::mutex mu_team;  // one host team for the decode side: two slots take turns on this path
+	std::unique_lock<std::mutex> lk_team(mu_team);
 	g_team_dec.run(n, h0.deflate ? zthreads : 1, [&](int i) {
 		const uint8_t *body = h_files + h_offsets[i] + 13;
 		const size_t blen = (size_t)(h_offsets[i + 1] - h_offsets[i]) - 13;
@@ -1493,9 +1541,10 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 			else { memcpy(dst, body, blen); psz[i] = (uint32_t)blen; }
 		}
 	});
+	lk_team.unlock();
 	const float t_inflate = (float)(now_ms() - t_inf0);
 	{  // device phase on the decode stream (no device lock: the HIP runtime is thread-safe)
-		hipStream_t st = g_ctx.stream_dec;
+		hipStream_t st = D.stream;
 		tl_inflate_ms = t_inflate;
 		// one strided copy of the used part of every staged payload (a copy per slice costs more in launches
 		// than in bytes)
@@ -1503,19 +1552,19 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		for (int i = 0; i < n; i++) used = std::max(used, (size_t)((psz[i] + 15u) & ~15u));
 		used = std::min(used, stride);
 		const double t_h0 = now_ms();
-		HIP_TRY(hipMemcpy2DAsync(g_ctx.d_payload.p, stride, stage, stride, used, (size_t)n, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(g_ctx.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-		uint16_t *d_img = images_on_device ? images : (uint16_t *)g_ctx.d_images.p;
-		HIP_TRY(hipEventRecord(g_ctx.ev_d0, st));
-		rc = decode_payload_locked((const uint8_t *)g_ctx.d_payload.p, stride, (const uint32_t *)g_ctx.d_sizes.p, n, h0.width,
-		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)g_ctx.d_status.p, st);
+		HIP_TRY(hipMemcpy2DAsync(D.d_payload.p, stride, stage, stride, used, (size_t)n, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(D.d_sizes.p, psz.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+		uint16_t *d_img = images_on_device ? images : (uint16_t *)D.d_images.p;
+		HIP_TRY(hipEventRecord(D.ev_d0, st));
+		rc = decode_payload_locked(D, (const uint8_t *)D.d_payload.p, stride, (const uint32_t *)D.d_sizes.p, n, h0.width,
+		                           h0.height, block_size, h0.fractal, d_img, (uint32_t *)D.d_status.p, st);
 		if (rc) return rc;
-		HIP_TRY(hipEventRecord(g_ctx.ev_d1, st));
-		HIP_TRY(hipMemcpyAsync(dst.data(), g_ctx.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipEventRecord(D.ev_d1, st));
+		HIP_TRY(hipMemcpyAsync(dst.data(), D.d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 		if (!images_on_device)
 			HIP_TRY(hipMemcpyAsync(images, d_img, (size_t)n * N * 2, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipEventElapsedTime(&tl_dec_kernel_ms, g_ctx.ev_d0, g_ctx.ev_d1));
+		HIP_TRY(hipEventElapsedTime(&tl_dec_kernel_ms, D.ev_d0, D.ev_d1));
 		if (getenv("CCT_TRACE"))
 			fprintf(stderr, "[cct] decode n=%d: inflate %.2f ms, h2d+kernel+sync %.2f ms (kernel %.2f), used %zu of stride %zu\n", n,
 			        t_inflate, now_ms() - t_h0, tl_dec_kernel_ms, used, stride);
@@ -1560,6 +1609,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
+	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -1577,6 +1627,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
+	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

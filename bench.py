@@ -231,7 +231,8 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     # two encode threads: the library gives the device lock back while a batch's files are still on the wire, so
     # the next batch's kernels start during that copy
-    pool_enc, pool_dec = ThreadPoolExecutor(2 if not args.no_overlap else 1), ThreadPoolExecutor(1)
+    # decode only: two decode threads, so that the archive upload of one batch runs under the kernels of the other (two decode slots)
+    pool_enc, pool_dec = ThreadPoolExecutor(2 if not args.no_overlap else 1), ThreadPoolExecutor(2 if (args.config == 5 and not args.no_overlap) else 1)
     overlap = not args.no_overlap
 
     def enc_step(i, k, record):

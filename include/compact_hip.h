@@ -16,8 +16,8 @@
  * (cct_encode_batch, cct_encode_batch_packed) takes one of two internal encode slots -- a
  * HIP stream with its own workspaces -- so two of them run side by side on the device and a
  * third waits (option "encode_slots" = 1: one at a time); decode calls (cct_decode_batch,
- * cct_zlib_decompress_batch) run on a stream of their own, one at a time, next to the
- * encodes; the size gather (cct_allgather_u32) has its own stream as well.  Everything else
+ * cct_zlib_decompress_batch) likewise take one of two decode slots ("decode_slots"), next to
+ * the encodes; the size gather (cct_allgather_u32) has its own stream as well.  Everything else
  * shares the main stream (= encode slot 0) under one mutex.  The streams are NOT ordered
  * against each other: every host-facing call is complete when it returns (cct_dev_memset
  * and the h2d/d2h copies included); only cct_encode_payload_dev / cct_decode_payload_dev

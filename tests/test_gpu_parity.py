@@ -693,3 +693,44 @@ def test_rccl_communicator_of_one(hip):
         parallel.barrier()
     finally:
         _ffi.check(L.cct_comm_destroy())
+
+
+def test_concurrent_encodes_and_decodes_use_their_slots(hip):
+    """Two encode calls and two decode calls at a time, from four host threads (the library gives each an encode / decode
+    slot with its own stream and workspaces): every result equals the serial one."""
+    from concurrent.futures import ThreadPoolExecutor
+    cfg = hip.default_config()
+    batches = [np.stack([gi.ct_phantom(10 * k + i, 256) for i in range(24)]) for k in range(4)]
+    serial = [hip.encode_batch(b, cfg) for b in batches]
+    for k, b in enumerate(batches):
+        assert np.array_equal(hip.decode_batch(serial[k], cfg), b)
+
+    def enc(k):
+        return [hip.encode_batch(batches[k], cfg) for _ in range(3)]
+
+    def dec(k):
+        return [hip.decode_batch(serial[k], cfg) for _ in range(3)]
+
+    with ThreadPoolExecutor(4) as pool:
+        fe = [pool.submit(enc, k) for k in (0, 1)]
+        fd = [pool.submit(dec, k) for k in (2, 3)]
+        for k, f in zip((0, 1), fe):
+            for files in f.result():
+                assert files == serial[k]
+        for k, f in zip((2, 3), fd):
+            for back in f.result():
+                assert np.array_equal(back, batches[k])
+    # one slot each must give the same
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    try:
+        _ffi.check(L.cct_set_option(b"encode_slots", 1))
+        _ffi.check(L.cct_set_option(b"decode_slots", 1))
+        with ThreadPoolExecutor(4) as pool:
+            fe = [pool.submit(enc, k) for k in (0, 1)]
+            fd = [pool.submit(dec, k) for k in (2, 3)]
+            assert all(files == serial[k] for k, f in zip((0, 1), fe) for files in f.result())
+            assert all(np.array_equal(back, batches[k]) for k, f in zip((2, 3), fd) for back in f.result())
+    finally:
+        _ffi.check(L.cct_set_option(b"encode_slots", 2))
+        _ffi.check(L.cct_set_option(b"decode_slots", 2))
