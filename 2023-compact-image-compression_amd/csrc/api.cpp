@@ -1229,6 +1229,10 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		// bounded workspaces: at most 2^28 payload bytes per pass (the corpus config is 3954 slices)
 		const int chunk = (int)std::max<size_t>(1, ((size_t)1 << 28) / stride);
 		tl_deflate_ms = 0; tl_d2h_ms = 0;
+		struct CopyGuard {  // an error return must not leave a copy into the caller's archive in flight
+			EncSlot &E; bool armed = false;
+			~CopyGuard() { if (armed && E.stream_copy) (void)hipStreamSynchronize(E.stream_copy); }
+		} copies_in_flight{E};
 		for (int c0 = 0; c0 < n; c0 += chunk) {
 			const int nc = std::min(chunk, n - c0);
 			HIP_TRY(hipEventRecord(E.ev_z0, E.stream));
@@ -1260,18 +1264,24 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			const uint64_t at = h_packed_offsets[c0];
 			if (at + f.exact > out_stride) return fail(CCT_E_CAP, "packed output needs %zu bytes", (size_t)(at + f.exact));
 			for (int i = 0; i < nc; i++) h_packed_offsets[c0 + i + 1] = h_packed_offsets[c0 + i] + osz[i];
-			if (nc == n && is_pinned_host(h_out + at, f.exact)) {
+			if (is_pinned_host(h_out + at, f.exact)) {
+				// page-locked archive: the files of this pass leave on the copy stream while the next pass (or, after the last
+				// one, the next batch) already runs its kernels
 				hipEvent_t done = nullptr;
 				if ((rc = files_to_pinned_archive_async(f, h_out + at, lk, &done))) return rc;
+				copies_in_flight.armed = true;
+				tl_d2h_ms += (float)(now_ms() - t_c0);
+				if (c0 + nc < n) continue;
 				if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 				const float t_defl = E.t_dev_deflate_ms;
 				const double t_unlock = now_ms();
 				lk.unlock();  // the slot is free for the next batch; only the copy stream still works for this one
 				HIP_TRY(hipEventSynchronize(done));
+				copies_in_flight.armed = false;
 				if (getenv("CCT_TRACE"))
 					fprintf(stderr, "[cct] encode n=%d: waited for a slot %.2f ms, held it %.2f ms (kernel %.2f, deflate %.2f), tail %.2f ms, t=%.2f\n", nc,
 					        t_lock0 - t_call0, t_unlock - t_lock0, tl_enc_kernel_ms, t_defl, now_ms() - t_unlock, t_lock0);
-				tl_d2h_ms = (float)(now_ms() - t_c0);  // (no lock: a float for cct_last_timings)
+				tl_d2h_ms += (float)(now_ms() - t_c0);  // (no lock: a float for cct_last_timings)
 				return CCT_OK;
 			}
 			double t_c1 = t_c0;
