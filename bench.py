@@ -406,8 +406,8 @@ def main():
             main_roof = pack
         what = "decode only" if decode_only else "encode to .cct + decode back"
         out = {
-            "metric": "MPixels/s encode+decode, 12-bit 512x512 CT batch, bytes-exact" if not decode_only
-            else "MPixels/s decode, 12-bit 512x512 CT batch, bytes-exact",
+            "metric": f"MPixels/s encode+decode, 12-bit {W}x{H} CT batch, bytes-exact" if not decode_only
+            else f"MPixels/s decode, 12-bit {W}x{H} CT batch, bytes-exact",
             "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",

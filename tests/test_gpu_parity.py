@@ -695,6 +695,42 @@ def test_rccl_communicator_of_one(hip):
         _ffi.check(L.cct_comm_destroy())
 
 
+def test_bench_two_ranks_on_one_device(hip, tmp_path):
+    """bench.py's N > 1 control flow with two real processes on this box's one GPU: rank-disjoint batches, the size gather after
+    every encode, barriers, max-over-ranks time, one JSON line from rank 0.  Only the collective is replaced (files instead of
+    RCCL, which refuses two ranks on one device): tests/bench_rank.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world, slices = 2, 32
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", CCT_TEST_EXCHANGE_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "bench_rank.py"), "--gpus", str(world),
+                                       "--steps", "4", "--warmup", "1", "--slices", str(slices)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, se[-2000:])
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    line = json.loads(lines0[0])
+    assert line["n_gpus"] == world and line["verified"] is True and line["scaling"] == "weak"
+    assert line["sizes_gathered"] == world * slices          # both ranks' sizes, in global slice order
+    assert "cpu_baseline" not in line                        # rank 0 at N = 1 only
+    px = world * slices * 512 * 512 * line["steps"]
+    assert abs(line["value"] - px / (line["ms_per_step"] * 1e-3 * line["steps"]) / 1e6) / line["value"] < 0.01
+
+
 def test_concurrent_encodes_and_decodes_use_their_slots(hip):
     """Two encode calls and two decode calls at a time, from four host threads (the library gives each an encode / decode
     slot with its own stream and workspaces): every result equals the serial one."""
