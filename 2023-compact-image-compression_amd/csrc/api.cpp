@@ -152,6 +152,14 @@ struct Context {
 	int zlib_threads = 0;
 	int wg_threads = 1024;
 	int dec_slots = N_DEC_SLOTS;  // option "decode_slots"
+	int inflate_lanes = 0;  // option "inflate_lanes": 256 / 512 lanes per stream in the INFLATE kernel, 0 = 512 unless an encode call is
+	                        // in flight (next to an encode batch the narrower workgroup is the faster one, see inflate_kernels.hip)
+	int last_inflate_lanes = 0;  // read-only option "last_inflate_lanes"
+};
+std::atomic<int> g_encodes_in_flight{0};
+struct EncodeInFlight {
+	EncodeInFlight() { g_encodes_in_flight.fetch_add(1, std::memory_order_relaxed); }
+	~EncodeInFlight() { g_encodes_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 };
 
 double now_ms()
@@ -161,6 +169,12 @@ double now_ms()
 }
 
 Context g_ctx;
+int inflate_lanes_now()
+{
+	const int lanes = g_ctx.inflate_lanes ? g_ctx.inflate_lanes : (g_encodes_in_flight.load(std::memory_order_relaxed) > 0 ? 256 : 512);
+	g_ctx.last_inflate_lanes = lanes;
+	return lanes;
+}
 EncSlot *g_enc = new EncSlot[N_ENC_SLOTS];
 DecSlot *g_dec = new DecSlot[N_DEC_SLOTS];
 void reset_ctx()
@@ -1165,6 +1179,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	// total), h_packed_offsets[n+1]; needs the device DEFLATE path (or deflate off)
 	const bool packed = h_packed_offsets != nullptr;
 	const double t_call0 = now_ms();
+	EncodeInFlight in_flight;  // decode calls that start meanwhile pick the INFLATE geometry that shares the device best
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if (!(g_ctx.ready && g_ctx.pid == getpid())) {  // first use in this process: bind the device
@@ -1406,7 +1421,7 @@ int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
 	ia.offsets = (const uint64_t *)D.d_archoffs.p; ia.skip = 0;
 	ia.out = (uint8_t *)D.d_payload.p; ia.out_stride = out_stride;
 	ia.out_sizes = (uint32_t *)D.d_sizes.p; ia.status = (uint32_t *)D.d_zstatus.p;
-	HIP_TRY(launch_inflate(ia, n, st));
+	HIP_TRY(launch_inflate(ia, n, st, inflate_lanes_now()));
 	HIP_TRY(hipMemcpyAsync(zst.data(), D.d_zstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(osz.data(), D.d_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1514,7 +1529,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		ia.out = (uint8_t *)D.d_payload.p; ia.out_stride = stride;
 		ia.out_sizes = (uint32_t *)D.d_sizes.p; ia.status = (uint32_t *)D.d_zstatus.p;
 		HIP_TRY(hipEventRecord(D.ev_d0, st));
-		HIP_TRY(launch_inflate(ia, n, st));
+		HIP_TRY(launch_inflate(ia, n, st, inflate_lanes_now()));
 		HIP_TRY(hipEventRecord(D.ev_d1, st));
 		uint16_t *d_img = images_on_device ? images : (uint16_t *)D.d_images.p;
 		hipEvent_t ev_k = D.ev_k_dec0, ev_k1 = D.ev_k_dec1;
@@ -1620,6 +1635,10 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
+	if (!strcmp(key, "inflate_lanes")) {
+		if (value != 0 && value != 256 && value != 512) return fail(CCT_E_ARG, "inflate_lanes must be 0 (automatic), 256 or 512");
+		g_ctx.inflate_lanes = value; return CCT_OK;
+	}
 	if (!strcmp(key, "wg_threads")) {
 		if (value != 256 && value != 512 && value != 1024) return fail(CCT_E_ARG, "wg_threads must be 256, 512 or 1024");
 		g_ctx.wg_threads = value; return CCT_OK;
@@ -1638,6 +1657,8 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
+	if (!strcmp(key, "inflate_lanes")) { *value = g_ctx.inflate_lanes; return CCT_OK; }
+	if (!strcmp(key, "last_inflate_lanes")) { *value = g_ctx.last_inflate_lanes; return CCT_OK; }
 	if (!strcmp(key, "wg_threads")) { *value = g_ctx.wg_threads; return CCT_OK; }
 	return fail(CCT_E_ARG, "unknown option %s", key);
 }

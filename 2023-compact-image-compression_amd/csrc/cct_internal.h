@@ -161,7 +161,8 @@ struct InflateArgs {
 	uint8_t *out; size_t out_stride;        // inflated payloads
 	uint32_t *out_sizes, *status;           // status: CCT_ST_ZLIB / CCT_ST_STREAM bits
 };
-hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st);
+// lanes: 256 or 512 per stream (512: faster alone, slower next to an encode batch; inflate_kernels.hip)
+hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st, int lanes);
 
 // ---- PackBits utility (packbits_kernels.hip) -------------------------------------------------
 hipError_t launch_packbits_encode(const uint8_t *d_in, const uint64_t *d_offsets, int n, int delta, uint32_t *d_ws, uint8_t *d_out,

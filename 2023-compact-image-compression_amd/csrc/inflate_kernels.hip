@@ -3,10 +3,10 @@
 // specified by the stream format, so any correct decoder returns the same bytes (and the Adler-32
 // trailer is verified like zlib does).
 //
-// One workgroup of 4 waves per stream.  The format carries no symbol index, so the position of symbol k+1 is
+// One workgroup of 8 waves per stream.  The format carries no symbol index, so the position of symbol k+1 is
 // only known after symbol k has been decoded; a single lane walking that chain spends ~10^3 cycles per symbol.
 // The workgroup breaks the chain speculatively (Huffman codes re-synchronise after a few symbols):
-//   * a round covers 256 segments of SEG_BITS (256) compressed bits, one per lane; lane 0 starts at the true position,
+//   * a round covers NT (512) segments of SEG_BITS (256) compressed bits, one per lane; lane 0 starts at the true position,
 //     the others at their segment boundary, and every lane decodes until it crosses into the next segment;
 //   * lanes then restart from where their predecessor really landed until no start moves any more (lane k is
 //     final after k passes at the latest; in practice 2-3 passes), which yields the true chain of the round;
@@ -35,18 +35,35 @@
 namespace cct {
 namespace {
 
-constexpr int NT = 256;                       // lanes per stream
-constexpr int NWV = NT / 64;                  // waves per stream
+// Lanes per stream: 512 when the decode has the device to itself (two waves per SIMD: the walk of one hides the LDS round trips
+// of the other; 1.66 -> 1.38 ms per 256 streams), 256 next to an encode batch (measured in the bench: with 512 lanes and 139 KB of
+// LDS per stream INFLATE ran 1.97 ms against 1.77 ms and the DEFLATE pass beside it 5.3 against 5.1 ms).  launch_inflate() picks.
+template <int LANES>
+struct Geo {
+	static constexpr int NT = LANES;                                  // lanes per stream
+	static constexpr int NWV = LANES / 64;                            // waves per stream
+	static constexpr int INF_IN = LANES >= 512 ? 32768 : 16384;       // staged input window (a round reads NT * SEG_BITS / 8 bytes + a chunk of slack)
+	static constexpr int ROUND_OUT_BUDGET = LANES >= 512 ? 28672 : 24576;  // output bytes of a round (ring = 32 KiB window + round)
+};
+#define GEO_CONSTANTS constexpr int NT = G::NT, NWV = G::NWV, INF_IN = G::INF_IN, ROUND_OUT_BUDGET = G::ROUND_OUT_BUDGET; (void)NT; (void)NWV; (void)INF_IN; (void)ROUND_OUT_BUDGET
 constexpr int INF_RING = 65536, INF_RMASK = INF_RING - 1, INF_FLUSH = 4096;
-constexpr int INF_IN = 16384, INF_CHUNK = 4096;
+constexpr int INF_CHUNK = 4096;
 constexpr int LL_BITS = 12;
 constexpr int D_BITS = 10;
 constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24, K_TWO = 1u << 26;
 constexpr int SEG_BITS = 256;                 // compressed bits per lane and round
-constexpr int ROUND_OUT_BUDGET = 24576;       // output bytes of a round
 constexpr int LANE_OUT_CAP = 16384;           // a lane stops (and ends the round) once it has produced this much
 constexpr int MLIST_CAP = 2048;               // LZ77 copies a round may hold (one lane alone: at most SEG_BITS / 2)
 constexpr uint32_t SEG_EOB = 1, SEG_BAD = 2, SEG_CUT = 4;
+template <class G>
+constexpr bool geo_ok()
+{
+	return 32768 + G::ROUND_OUT_BUDGET <= INF_RING          // the ring holds the 32 KiB window and the output of a round
+	       && LANE_OUT_CAP + 512 <= G::ROUND_OUT_BUDGET        // lane 0 alone always fits a round
+	       && G::NT * SEG_BITS / 8 + 32 + INF_CHUNK <= G::INF_IN  // the staged window covers a round's input
+	       && G::NWV >= 4;                                     // build_tables: a wave takes at most two chunks of symbols
+}
+static_assert(geo_ok<Geo<256>>() && geo_ok<Geo<512>>(), "INFLATE geometry");
 
 __constant__ uint16_t c_lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 __constant__ uint8_t c_lext[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -61,7 +78,9 @@ struct CanonLds {
 	uint32_t lim[16], adj[16], offs[16];
 };
 
+template <class G>
 struct InfShared {
+	static constexpr int NT = G::NT, NWV = G::NWV, INF_IN = G::INF_IN;
 	uint8_t ring[INF_RING];
 	alignas(16) uint8_t inbuf[INF_IN];
 	// root decode tables (LL_BITS / D_BITS); entry layout at ll_entry() below; 0 = no code of root length or less
@@ -92,8 +111,10 @@ struct BitReader {    // workgroup-uniform reader used for headers; every lane h
 	int cnt;
 };
 
-__device__ __forceinline__ void stage_chunk(InfShared &S, BitReader &br)
+template <class G>
+__device__ __forceinline__ void stage_chunk(InfShared<G> &S, BitReader &br)
 {
+	GEO_CONSTANTS;
 	__syncthreads();  // nobody still reads the chunk that is about to be replaced
 	uint4 *dst = reinterpret_cast<uint4 *>(S.inbuf + (br.staged_end & (INF_IN - 1)));
 	const uint4 *srcv = reinterpret_cast<const uint4 *>(br.src + br.staged_end);
@@ -106,8 +127,10 @@ __device__ __forceinline__ void stage_chunk(InfShared &S, BitReader &br)
 	__syncthreads();
 }
 
-__device__ __forceinline__ void refill(InfShared &S, BitReader &br)
+template <class G>
+__device__ __forceinline__ void refill(InfShared<G> &S, BitReader &br)
 {
+	GEO_CONSTANTS;
 	while (br.cnt <= 32) {
 		while (br.bytepos + 4 > br.staged_end) stage_chunk(S, br);
 		const uint32_t w = *reinterpret_cast<const uint32_t *>(S.inbuf + (br.bytepos & (INF_IN - 1)));
@@ -161,7 +184,8 @@ __device__ __forceinline__ bool canon_from_counts(const uint32_t *cnt, CanonLds 
 }
 
 // code-length alphabet (19 symbols, <= 7 bits) from S.lens[0..19); S.ok = 0 if zlib would refuse the set
-__device__ void build_cl(InfShared &S)
+template <class G>
+__device__ void build_cl(InfShared<G> &S)
 {
 	if (threadIdx.x < 16) S.cnt[threadIdx.x] = 0;
 	__syncthreads();
@@ -192,14 +216,16 @@ __device__ void build_cl(InfShared &S)
 
 // decode-table entries.  bits 0-3: code bits to drop (both literals of a pair), 4-7: literal: bits of the first literal;
 // length / distance: extra bits, 8-23: literals (first at 8, second at 16) or base value, 24-25 kind, 26: two literals
-__device__ __forceinline__ uint32_t ll_entry(const InfShared &S, int s, int bits)
+template <class G>
+__device__ __forceinline__ uint32_t ll_entry(const InfShared<G> &S, int s, int bits)
 {
 	if (s < 256) return K_LIT | ((uint32_t)s << 8) | ((uint32_t)bits << 4) | (uint32_t)bits;
 	if (s == 256) return K_EOB | (uint32_t)bits;
 	if (s - 257 >= 29) return 0;  // 286, 287: invalid
 	return K_LEN | ((uint32_t)S.lbase[s - 257] << 8) | ((uint32_t)S.lext[s - 257] << 4) | (uint32_t)bits;
 }
-__device__ __forceinline__ uint32_t d_entry(const InfShared &S, int s, int bits)
+template <class G>
+__device__ __forceinline__ uint32_t d_entry(const InfShared<G> &S, int s, int bits)
 {
 	if (s >= 30) return 0;
 	return K_LEN | ((uint32_t)S.dbase[s] << 8) | ((uint32_t)S.dext[s] << 4) | (uint32_t)bits;
@@ -208,9 +234,10 @@ __device__ __forceinline__ uint32_t d_entry(const InfShared &S, int s, int bits)
 // Lookup tables from S.lens[0..n), by the whole workgroup.  sent[]: the entry of every coded symbol, in (length, symbol)
 // order.  Root table: FB bits; a literal/length entry holds two literals when both codes fit.  S.ok = 0: zlib would
 // refuse the code lengths.
-template <bool DIST>
-__device__ void build_tables(InfShared &S, int n)
+template <bool DIST, class G>
+__device__ void build_tables(InfShared<G> &S, int n)
 {
+	GEO_CONSTANTS;
 	constexpr int FB = DIST ? D_BITS : LL_BITS;
 	uint32_t *tab = DIST ? S.d_tab : S.ll_tab;
 	uint32_t *sent = DIST ? S.d_sent : S.ll_sent;
@@ -284,15 +311,19 @@ __device__ void build_tables(InfShared &S, int n)
 // per-lane bit reader over the staged input; bit positions are 32-bit offsets from the round's origin dword
 struct LaneBits { uint64_t buf; int cnt; uint32_t next; };  // next = dword index relative to br.src
 
-__device__ __forceinline__ void lane_init(const InfShared &S, LaneBits &lb, uint32_t org_dword, uint32_t rel_bit)
+template <class G>
+__device__ __forceinline__ void lane_init(const InfShared<G> &S, LaneBits &lb, uint32_t org_dword, uint32_t rel_bit)
 {
+	GEO_CONSTANTS;
 	const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
 	const uint32_t idx = org_dword + (rel_bit >> 5), sh = rel_bit & 31u;
 	const uint64_t w = (uint64_t)in32[idx & (INF_IN / 4 - 1)] | ((uint64_t)in32[(idx + 1) & (INF_IN / 4 - 1)] << 32);
 	lb.buf = w >> sh; lb.cnt = 64 - (int)sh; lb.next = idx + 2;
 }
-__device__ __forceinline__ void lane_refill(const InfShared &S, LaneBits &lb)
+template <class G>
+__device__ __forceinline__ void lane_refill(const InfShared<G> &S, LaneBits &lb)
 {
+	GEO_CONSTANTS;
 	if (lb.cnt <= 32) {
 		const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
 		lb.buf |= (uint64_t)in32[lb.next & (INF_IN / 4 - 1)] << lb.cnt;
@@ -310,11 +341,12 @@ __device__ __forceinline__ uint32_t lane_pos(const LaneBits &lb, uint32_t org_dw
 // on how a lane got there (restarts compare landings): the second literal of a pair is taken only if it starts before
 // `end`, which makes the landing the first symbol boundary at or after `end` whatever the pairing.
 constexpr int FAST_STEPS = 3;
-template <bool EMIT>
-__device__ __forceinline__ void walk_segment(InfShared &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t &land,
+template <bool EMIT, class G>
+__device__ __forceinline__ void walk_segment(InfShared<G> &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t &land,
                                              uint32_t &nbytes, uint32_t &nmatch, uint32_t &flags, uint32_t o, uint32_t mi,
                                              uint32_t *steps = nullptr)
 {
+	GEO_CONSTANTS;
 	const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
 	LaneBits lb;
 	lane_init(S, lb, org_dword, start);
@@ -415,8 +447,8 @@ constexpr int CL_SEG = 16;
 constexpr uint32_t CL_BAD = 1, CL_OVER = 2;
 constexpr uint8_t CL_PREV = 0xFF;  // marker: same as the entry before (lengths are <= 15)
 
-template <bool EMIT>
-__device__ __forceinline__ void cl_walk(InfShared &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t limit,
+template <bool EMIT, class G>
+__device__ __forceinline__ void cl_walk(InfShared<G> &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t limit,
                                         uint32_t idx_base, uint32_t &land, uint32_t &cnt, uint32_t &flags)
 {
 	LaneBits lb;
@@ -443,10 +475,12 @@ __device__ __forceinline__ void cl_walk(InfShared &S, uint32_t org_dword, uint32
 	land = lane_pos(lb, org_dword);
 }
 
-// smallest lane index (0..255) whose predicate is set, NT if none; all lanes call it (one barrier inside, and
+// smallest lane index (0..NT-1) whose predicate is set, NT if none; all lanes call it (one barrier inside, and
 // what was written to LDS before the call is visible to everybody after it)
-__device__ __forceinline__ int first_lane_with(InfShared &S, bool pred, int slot)
+template <class G>
+__device__ __forceinline__ int first_lane_with(InfShared<G> &S, bool pred, int slot)
 {
+	GEO_CONSTANTS;
 	const uint64_t bal = __ballot(pred);
 	const int wave = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 0) S.wred[slot * NWV + wave] = bal ? (uint32_t)(wave * 64 + __ffsll((long long)bal) - 1) : (uint32_t)NT;
@@ -463,14 +497,15 @@ enum { P_M_SETUP, P_HDR, P_TABLES, P_T_CLLENS, P_T_CL, P_T_CLWALK, P_T_LL, P_STA
 #define PROF_T(slot) do { if (PROF) { const long long t_ = clock64(); prof[slot] += (uint64_t)(t_ - tprev); tprev = t_; } } while (0)
 #define PROF_C(slot, v) do { if (PROF) prof[slot] += (uint64_t)(v); } while (0)
 
-template <bool PROF>
-__global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a, uint64_t *prof_out)
+template <class G, bool PROF>
+__global__ void __launch_bounds__(G::NT) inflate_kernel(InflateArgs a, uint64_t *prof_out)
 {
+	GEO_CONSTANTS;
 	uint64_t prof[P_N] = {};
 	long long tprev = PROF ? clock64() : 0;
 	const long long tstart = tprev;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-	InfShared &S = *reinterpret_cast<InfShared *>(smem_raw);
+	InfShared<G> &S = *reinterpret_cast<InfShared<G> *>(smem_raw);
 	const int s = blockIdx.x;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint64_t f0 = a.offsets[s] + (uint64_t)a.skip, f1 = a.offsets[s + 1];
@@ -860,9 +895,10 @@ __global__ void __launch_bounds__(NT) inflate_kernel(InflateArgs a, uint64_t *pr
 
 }  // namespace
 
-hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st)
+template <class G>
+static hipError_t launch_inflate_geo(const InflateArgs &a, int n, hipStream_t st)
 {
-	const size_t lds = sizeof(InfShared);
+	const size_t lds = sizeof(InfShared<G>);
 	static const bool want_prof = getenv("CCT_INF_PROF") != nullptr;
 	if (want_prof) {  // tuning runs only: synchronises and prints per-phase averages
 		static const char *names[P_N] = {"match_setup", "hdr", "tables(rest)", "t_cllens", "t_buildcl", "t_clwalk", "t_ll", "stage", "walk0", "restart", "scan", "emit", "match", "flush", "TOTAL", "#blocks", "#rounds",
@@ -871,14 +907,14 @@ hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st)
 		uint64_t *d_prof = nullptr;
 		hipError_t e = hipMalloc(&d_prof, (size_t)n * P_N * 8);
 		if (e != hipSuccess) return e;
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(inflate_kernel<true>, dim3(n), dim3(NT), lds, st, a, d_prof);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL((inflate_kernel<G, true>), dim3(n), dim3(G::NT), lds, st, a, d_prof);
 		std::vector<uint64_t> h((size_t)n * P_N);
 		e = hipMemcpyAsync(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipStreamSynchronize(st);
 		(void)hipFree(d_prof);
 		if (e != hipSuccess) return e;
-		fprintf(stderr, "[inflate prof] n=%d, per stream:", n);
+		fprintf(stderr, "[inflate prof] n=%d lanes=%d, per stream:", n, G::NT);
 		for (int i = 0; i < P_N; i++) {
 			double sum = 0;
 			for (int s = 0; s < n; s++) sum += (double)h[(size_t)s * P_N + i];
@@ -887,11 +923,16 @@ hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st)
 		fprintf(stderr, "\n");
 		return hipSuccess;
 	}
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<false>),
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel<G, false>),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(inflate_kernel<false>, dim3(n), dim3(NT), lds, st, a, (uint64_t *)nullptr);
+	hipLaunchKernelGGL((inflate_kernel<G, false>), dim3(n), dim3(G::NT), lds, st, a, (uint64_t *)nullptr);
 	return hipGetLastError();
+}
+
+hipError_t launch_inflate(const InflateArgs &a, int n, hipStream_t st, int lanes)
+{
+	return lanes >= 512 ? launch_inflate_geo<Geo<512>>(a, n, st) : launch_inflate_geo<Geo<256>>(a, n, st);
 }
 
 }  // namespace cct

@@ -229,7 +229,11 @@ int cct_packbits_decode_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
  * on the device path, host wall on the libz path), [3] INFLATE (likewise), [4] decode kernel (HIP events),
  * [5] reserved. */
 int cct_last_timings(float *out6);
-int cct_set_option(const char *key, int value);  /* "zlib_threads", "wg_threads", ... */
+/* Options: "encode_slots" / "decode_slots" (1 or 2 batches on the device at a time), "device_deflate" / "device_inflate"
+ * (0: that stage on the host thread team of "zlib_threads" threads), "inflate_lanes" (lanes per stream of the INFLATE kernel:
+ * 256, 512, or 0 = 512 unless an encode call is in flight when the decode starts; "last_inflate_lanes" reads back the choice),
+ * "tile_path", "deflate_graph", "wg_threads", "pipe_tpw", "pipe_timing" (kernel choice and tuning). */
+int cct_set_option(const char *key, int value);
 int cct_get_option(const char *key, int *value);
 
 #ifdef __cplusplus

@@ -11,11 +11,16 @@ import golden_inputs as gi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def hip():
+@pytest.fixture(scope="module", params=[256, 512], ids=["inflate256", "inflate512"])
+def hip(request):
+    """Every test of this module runs with both geometries of the INFLATE kernel (256 / 512 lanes per stream; the library
+    picks 512 unless an encode call is in flight, option "inflate_lanes" forces one)."""
     import cct_hip
+    from cct_hip import _ffi
     cct_hip.device_info()
-    return cct_hip
+    _ffi.check(_ffi.lib().cct_set_option(b"inflate_lanes", request.param))
+    yield cct_hip
+    _ffi.check(_ffi.lib().cct_set_option(b"inflate_lanes", 0))
 
 
 def _check(hip, blobs):
@@ -254,3 +259,25 @@ def test_device_inflate_agrees_with_zlib_on_damaged_streams(hip):
            if (want is None) != (got is None) or (want is not None and got != want)]
     assert not bad, f"{len(bad)} of {len(streams)} damaged streams disagree with zlib, first {bad[:5]}"
     assert sum(w is not None for w in expect) > 0 and sum(w is None for w in expect) > len(expect) // 2
+
+
+def test_inflate_geometry_choice(hip):
+    """Forced by the option, the kernel runs with that many lanes; left alone (0) a decode with no encode call in flight takes 512."""
+    import ctypes as C
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    cfg = hip.default_config()
+    files = hip.encode_batch(np.stack([gi.ct_phantom(s, 256) for s in (1, 2)]), cfg)
+    forced, last = C.c_int(0), C.c_int(0)
+    _ffi.check(L.cct_get_option(b"inflate_lanes", C.byref(forced)))
+    hip.decode_batch(files, cfg)
+    _ffi.check(L.cct_get_option(b"last_inflate_lanes", C.byref(last)))
+    assert last.value == forced.value
+    try:
+        _ffi.check(L.cct_set_option(b"inflate_lanes", 0))
+        hip.decode_batch(files, cfg)
+        _ffi.check(L.cct_get_option(b"last_inflate_lanes", C.byref(last)))
+        assert last.value == 512
+        assert L.cct_set_option(b"inflate_lanes", 128) != 0
+    finally:
+        _ffi.check(L.cct_set_option(b"inflate_lanes", forced.value))
