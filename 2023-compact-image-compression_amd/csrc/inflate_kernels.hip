@@ -439,40 +439,109 @@ __device__ __forceinline__ void walk_segment(InfShared<G> &S, uint32_t org_dword
 	land = p;
 }
 
-// The code-length sequence of a dynamic block header (<= 316 entries, run-length coded with the 19-symbol code)
-// is the same kind of chain as the block body, so wave 0 decodes it the same way: 64 segments of CL_SEG bits,
-// restarts until no start moves, prefix sum of the entry counts, second walk that writes S.lens.  A "repeat the
-// previous length" symbol (16) writes markers that a scan resolves afterwards.
-constexpr int CL_SEG = 16;
+// The code-length sequence of a dynamic block header (<= 316 entries, run-length coded with the 19-symbol code) is one
+// more dependent chain: where symbol k + 1 starts is known after symbol k.  It is short (<= 4424 bits), so instead of
+// speculating the whole workgroup ranks the list: every bit position of a CL_WIN-bit window looks up "the symbol that would
+// start here" (next position, entries produced), nine rounds of pointer doubling make that "2^k symbols on", and before
+// each doubling the positions already known to be on the true chain (position 0 at first) mark the position 2^k symbols
+// after them with its entry index.  After nine rounds every chain symbol within 511 symbols of the start is marked -- more than
+// the 316 entries a sequence can have -- and the marked positions write their entries.  A "repeat the previous length"
+// symbol (16) writes markers that a scan resolves afterwards.  The arrays live in the copy list, idle while a header is parsed.
+constexpr int CL_WIN = 2048, CL_WINX = CL_WIN + 16;  // positions CL_WIN.. are "outside": a symbol is at most 14 bits long
+constexpr int CL_LEVELS = 9;
 constexpr uint32_t CL_BAD = 1, CL_OVER = 2;
+constexpr uint16_t CL_NONE = 0xFFFF, CL_SAT = 0x7FFF;
 constexpr uint8_t CL_PREV = 0xFF;  // marker: same as the entry before (lengths are <= 15)
+static_assert(3 * CL_WINX * sizeof(uint16_t) <= MLIST_CAP * sizeof(uint2), "the ranking arrays fit the copy list");
 
-template <bool EMIT, class G>
-__device__ __forceinline__ void cl_walk(InfShared<G> &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t limit,
-                                        uint32_t idx_base, uint32_t &land, uint32_t &cnt, uint32_t &flags)
+// symbol that starts at bit `bit` (relative to br.src): bits it takes (0: no such code) and entries it produces / their value
+template <class G>
+__device__ __forceinline__ uint32_t cl_symbol(const InfShared<G> &S, uint64_t bit, uint32_t &rep, uint8_t &val)
 {
-	LaneBits lb;
-	lane_init(S, lb, org_dword, start);
-	cnt = 0; flags = 0;
-	while (lane_pos(lb, org_dword) < end) {
-		if (EMIT && cnt == limit) break;  // the sequence is complete: the block body starts here
-		lane_refill(S, lb);
-		const uint32_t lo = (uint32_t)lb.buf;
-		const uint32_t ce = S.cl_tab[lo & ((1u << CL_BITS) - 1u)];
-		if (ce == 0) { flags = CL_BAD; break; }
-		const uint32_t sym = ce >> 3, cb = ce & 7u;
-		const uint32_t xb = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
-		const uint32_t xv = (lo >> cb) & ((1u << xb) - 1u);
-		const uint32_t rep = sym < 16 ? 1u : sym == 18 ? 11u + xv : 3u + xv;
-		if (EMIT) {
-			if (rep > limit - cnt) { flags = CL_OVER; break; }  // repeat beyond the last entry
-			const uint8_t v = sym < 16 ? (uint8_t)sym : sym == 16 ? CL_PREV : (uint8_t)0;
-			for (uint32_t t = 0; t < rep; t++) S.lens[idx_base + cnt + t] = v;
+	GEO_CONSTANTS;
+	const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
+	const uint32_t idx = (uint32_t)(bit >> 5), sh = (uint32_t)bit & 31u;
+	const uint64_t w = (uint64_t)in32[idx & (INF_IN / 4 - 1)] | ((uint64_t)in32[(idx + 1) & (INF_IN / 4 - 1)] << 32);
+	const uint32_t lo = (uint32_t)(w >> sh);
+	const uint32_t ce = S.cl_tab[lo & ((1u << CL_BITS) - 1u)];
+	if (ce == 0) { rep = 0; val = 0; return 0; }
+	const uint32_t sym = ce >> 3, cb = ce & 7u;
+	const uint32_t xb = sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+	const uint32_t xv = (lo >> cb) & ((1u << xb) - 1u);
+	rep = sym < 16 ? 1u : sym == 18 ? 11u + xv : 3u + xv;
+	val = sym < 16 ? (uint8_t)sym : sym == 16 ? CL_PREV : (uint8_t)0;
+	return cb + xb;
+}
+
+// Decodes `total` entries starting at bit b0 into S.lens (CL_PREV markers unresolved); returns 0 and the bit position after
+// the sequence, or an error flag.  Called by the whole workgroup, uniform result.
+template <class G>
+__device__ uint32_t cl_sequence(InfShared<G> &S, uint64_t b0, uint32_t total, uint64_t &bend)
+{
+	GEO_CONSTANTS;
+	constexpr int PER = CL_WIN / NT;  // window positions per lane
+	uint16_t *up = reinterpret_cast<uint16_t *>(S.mlist), *sm = up + CL_WINX, *ix = sm + CL_WINX;
+	const int tid = threadIdx.x;
+	uint64_t bp = b0;
+	uint32_t done = 0;
+	for (;;) {
+		const uint32_t remaining = total - done;
+		for (int i = tid; i < CL_WINX; i += NT) {
+			uint32_t u = (uint32_t)i, rep = 0;
+			if (i < CL_WIN) {
+				uint8_t v;
+				u += cl_symbol(S, bp + (uint64_t)i, rep, v);  // a position without a code points at itself
+			}
+			up[i] = (uint16_t)u; sm[i] = (uint16_t)rep; ix[i] = i == 0 ? (uint16_t)0 : CL_NONE;
 		}
-		lb.buf >>= (cb + xb); lb.cnt -= (int)(cb + xb);
-		cnt += rep;
+		if (tid == 0) { S.rres[0] = 0xFFFFFFFFu; S.rres[1] = 0xFFFFFFFFu; S.rres[2] = 0; }
+		__syncthreads();
+		for (int level = 0; level < CL_LEVELS; level++) {
+			// a position marked during this very loop may or may not be seen by another lane: either way what that lane writes is
+			// a true chain position with its true index
+#pragma unroll
+			for (int k = 0; k < PER; k++) {
+				const int i = tid + k * NT;
+				const uint32_t x = ix[i];
+				if (x != CL_NONE) {
+					const uint32_t j = up[i];
+					if (j != (uint32_t)i) ix[j] = (uint16_t)min(x + (uint32_t)sm[i], (uint32_t)CL_SAT);
+				}
+			}
+			__syncthreads();
+			uint16_t nu[PER], ns[PER];
+#pragma unroll
+			for (int k = 0; k < PER; k++) {
+				const int i = tid + k * NT;
+				const uint32_t j = up[i];
+				nu[k] = up[j];
+				ns[k] = (uint16_t)min((uint32_t)sm[i] + (uint32_t)sm[j], (uint32_t)CL_SAT);
+			}
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < PER; k++) { const int i = tid + k * NT; up[i] = nu[k]; sm[i] = ns[k]; }
+			__syncthreads();
+		}
+		// marked positions before the end of the sequence write their entries; the one AT the end is where the block body starts
+		uint32_t fl = 0;
+		for (int i = tid; i < CL_WINX; i += NT) {
+			const uint32_t x = ix[i];
+			if (x == CL_NONE || x > remaining) continue;
+			if (x == remaining) { S.rres[0] = (uint32_t)i; continue; }          // unique: every symbol produces an entry
+			if (i >= CL_WIN) { S.rres[1] = (uint32_t)i | (x << 16); continue; }  // the chain leaves the window here (unique as well)
+			uint32_t rep; uint8_t v;
+			if (cl_symbol(S, bp + (uint64_t)i, rep, v) == 0) { fl |= CL_BAD; continue; }
+			if (rep > remaining - x) { fl |= CL_OVER; continue; }               // repeat beyond the last entry
+			for (uint32_t t = 0; t < rep; t++) S.lens[done + x + t] = v;
+		}
+		if (__syncthreads_or(fl != 0)) return CL_BAD;
+		const uint32_t endpos = S.rres[0], cont = S.rres[1];
+		__syncthreads();  // everybody has read the result slots before the next window resets them
+		if (endpos != 0xFFFFFFFFu) { bend = bp + endpos; return 0; }
+		if (cont == 0xFFFFFFFFu || (cont >> 16) == 0) return CL_BAD;  // cannot happen for a chain without a bad position
+		bp += cont & 0xFFFFu;
+		done += cont >> 16;
 	}
-	land = lane_pos(lb, org_dword);
 }
 
 // smallest lane index (0..NT-1) whose predicate is set, NT if none; all lanes call it (one barrier inside, and
@@ -620,43 +689,10 @@ __global__ void __launch_bounds__(G::NT) inflate_kernel(InflateArgs a, uint64_t 
 				while (br.bytepos + 2048 > br.staged_end) stage_chunk(S, br);  // the sequence is < 700 bytes
 				const uint32_t total = (uint32_t)(nlen + ndist);
 				const uint64_t b0 = br.bytepos * 8u - (uint64_t)br.cnt;
-				if (wave == 0) {  // the other waves wait at the barrier below
-					uint32_t idx = 0, lerr = 0;
-					uint64_t bp = b0;
-					while (idx < total && !lerr) {
-						const uint32_t org_dword = (uint32_t)(bp >> 5), org_bit = (uint32_t)bp & 31u;
-						const uint32_t nominal = org_bit + (uint32_t)lane * CL_SEG, seg_end = nominal + CL_SEG;
-						uint32_t start = nominal, land, cnt, fl;
-						cl_walk<false>(S, org_dword, start, seg_end, 0, 0, land, cnt, fl);
-						int first;
-						for (;;) {  // restart from where the previous lane really landed until nothing moves
-							const uint32_t pl = __shfl_up(land, 1, 64);
-							const uint64_t flagged = __ballot(fl != 0);
-							first = flagged ? __ffsll((long long)flagged) - 1 : 64;
-							const bool moved = lane > 0 && lane <= first && pl != start;
-							if (!__ballot(moved)) break;
-							if (moved) { start = pl; cl_walk<false>(S, org_dword, start, seg_end, 0, 0, land, cnt, fl); }
-						}
-						uint32_t inc = cnt;  // entries up to and including this lane
-#pragma unroll
-						for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-						const uint32_t remaining = total - idx, base = inc - cnt;
-						const bool mine = lane <= first && base < remaining;
-						uint32_t eland = land, ecnt = 0, efl = 0;
-						if (mine) cl_walk<true>(S, org_dword, start, seg_end, remaining - base, idx + base, eland, ecnt, efl);
-						if (__ballot(mine && efl != 0)) { lerr = 1; break; }
-						const uint64_t done = __ballot(mine && base + ecnt >= remaining);  // the lane that wrote the last entry
-						if (done) {
-							const int le = __ffsll((long long)done) - 1;
-							idx = total;
-							bp = (uint64_t)org_dword * 32u + __shfl(eland, le, 64);
-						} else {  // 64 segments were not enough (or an invalid code came first, caught above)
-							if (first < 64) { lerr = 1; break; }
-							idx += __shfl(inc, 63, 64);
-							bp = (uint64_t)org_dword * 32u + __shfl(land, 63, 64);
-						}
-					}
-					__builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+				uint64_t bp = b0;
+				const uint32_t cl_err = cl_sequence(S, b0, total, bp);
+				if (wave == 0) {
+					uint32_t lerr = cl_err;
 					if (!lerr) {  // "same as the entry before": every lane owns five consecutive entries
 						uint8_t v[5];
 						uint32_t lastv = 0x100;  // last definite value in this lane's stretch (0x100: none)
