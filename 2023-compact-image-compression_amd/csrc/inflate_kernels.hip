@@ -446,13 +446,13 @@ __device__ __forceinline__ void walk_segment(InfShared<G> &S, uint32_t org_dword
 // each doubling the positions already known to be on the true chain (position 0 at first) mark the position 2^k symbols
 // after them with its entry index.  After nine rounds every chain symbol within 511 symbols of the start is marked -- more than
 // the 316 entries a sequence can have -- and the marked positions write their entries.  A "repeat the previous length"
-// symbol (16) writes markers that a scan resolves afterwards.  The arrays live in the copy list, idle while a header is parsed.
+// symbol (16) writes markers that a scan resolves afterwards.  The arrays live in the copy list and the root tables, idle while a header is parsed.
 constexpr int CL_WIN = 2048, CL_WINX = CL_WIN + 16;  // positions CL_WIN.. are "outside": a symbol is at most 14 bits long
 constexpr int CL_LEVELS = 9;
 constexpr uint32_t CL_BAD = 1, CL_OVER = 2;
 constexpr uint16_t CL_NONE = 0xFFFF, CL_SAT = 0x7FFF;
 constexpr uint8_t CL_PREV = 0xFF;  // marker: same as the entry before (lengths are <= 15)
-static_assert(3 * CL_WINX * sizeof(uint16_t) <= MLIST_CAP * sizeof(uint2), "the ranking arrays fit the copy list");
+static_assert(CL_WINX * sizeof(uint16_t) <= MLIST_CAP * sizeof(uint2) && 2 * CL_WINX <= (1 << LL_BITS) + (1 << D_BITS), "the ranking arrays fit the copy list and the root tables");
 
 // symbol that starts at bit `bit` (relative to br.src): bits it takes (0: no such code) and entries it produces / their value
 template <class G>
@@ -480,7 +480,10 @@ __device__ uint32_t cl_sequence(InfShared<G> &S, uint64_t b0, uint32_t total, ui
 {
 	GEO_CONSTANTS;
 	constexpr int PER = CL_WIN / NT;  // window positions per lane
-	uint16_t *up = reinterpret_cast<uint16_t *>(S.mlist), *sm = up + CL_WINX, *ix = sm + CL_WINX;
+	// (next position | entries << 16) per position, two copies (a round reads one and writes the other: one barrier per round) in
+	// the root tables, which are dead while a header is parsed; the chain marks (entry index, CL_NONE = not on the chain) in the copy list
+	uint32_t *A = S.ll_tab, *B = S.ll_tab + CL_WINX;
+	uint16_t *ix = reinterpret_cast<uint16_t *>(S.mlist);
 	const int tid = threadIdx.x;
 	uint64_t bp = b0;
 	uint32_t done = 0;
@@ -491,35 +494,25 @@ __device__ uint32_t cl_sequence(InfShared<G> &S, uint64_t b0, uint32_t total, ui
 			if (i < CL_WIN) {
 				uint8_t v;
 				u += cl_symbol(S, bp + (uint64_t)i, rep, v);  // a position without a code points at itself
-			}
-			up[i] = (uint16_t)u; sm[i] = (uint16_t)rep; ix[i] = i == 0 ? (uint16_t)0 : CL_NONE;
+			} else B[i] = u;                                   // outside positions never change
+			A[i] = u | (rep << 16);
+			ix[i] = i == 0 ? (uint16_t)0 : CL_NONE;
 		}
 		if (tid == 0) { S.rres[0] = 0xFFFFFFFFu; S.rres[1] = 0xFFFFFFFFu; S.rres[2] = 0; }
 		__syncthreads();
 		for (int level = 0; level < CL_LEVELS; level++) {
-			// a position marked during this very loop may or may not be seen by another lane: either way what that lane writes is
+			// a position marked during this very round may or may not be seen by another lane: either way what that lane writes is
 			// a true chain position with its true index
 #pragma unroll
 			for (int k = 0; k < PER; k++) {
 				const int i = tid + k * NT;
+				const uint32_t w = A[i], j = w & 0xFFFFu;
+				const uint32_t wj = A[j];
 				const uint32_t x = ix[i];
-				if (x != CL_NONE) {
-					const uint32_t j = up[i];
-					if (j != (uint32_t)i) ix[j] = (uint16_t)min(x + (uint32_t)sm[i], (uint32_t)CL_SAT);
-				}
+				B[i] = (wj & 0xFFFFu) | (min((w >> 16) + (wj >> 16), (uint32_t)CL_SAT) << 16);
+				if (x != CL_NONE && j != (uint32_t)i) ix[j] = (uint16_t)min(x + (w >> 16), (uint32_t)CL_SAT);
 			}
-			__syncthreads();
-			uint16_t nu[PER], ns[PER];
-#pragma unroll
-			for (int k = 0; k < PER; k++) {
-				const int i = tid + k * NT;
-				const uint32_t j = up[i];
-				nu[k] = up[j];
-				ns[k] = (uint16_t)min((uint32_t)sm[i] + (uint32_t)sm[j], (uint32_t)CL_SAT);
-			}
-			__syncthreads();
-#pragma unroll
-			for (int k = 0; k < PER; k++) { const int i = tid + k * NT; up[i] = nu[k]; sm[i] = ns[k]; }
+			uint32_t *t = A; A = B; B = t;
 			__syncthreads();
 		}
 		// marked positions before the end of the sequence write their entries; the one AT the end is where the block body starts
@@ -674,10 +667,20 @@ __global__ void __launch_bounds__(G::NT) inflate_kernel(InflateArgs a, uint64_t 
 			__syncthreads();
 			if (tid < 19) S.lens[tid] = 0;
 			__syncthreads();
-			for (int i = 0; i < ncode; i++) {
+			{  // ncode 3-bit fields, one lane each, read at their bit offsets
+				while (br.bytepos + 16 > br.staged_end) stage_chunk(S, br);
+				const uint64_t f0b = br.bytepos * 8u - (uint64_t)br.cnt;
+				if (tid < ncode) {
+					const uint32_t *in32 = reinterpret_cast<const uint32_t *>(S.inbuf);
+					const uint64_t bit = f0b + 3u * (uint32_t)tid;
+					const uint32_t idx = (uint32_t)(bit >> 5), sh = (uint32_t)bit & 31u;
+					const uint64_t w = (uint64_t)in32[idx & (INF_IN / 4 - 1)] | ((uint64_t)in32[(idx + 1) & (INF_IN / 4 - 1)] << 32);
+					S.lens[c_clorder[tid]] = (uint8_t)((w >> sh) & 7u);
+				}
+				const uint64_t f1b = f0b + 3u * (uint32_t)ncode;
+				br.bytepos = (f1b >> 5) * 4u; br.buf = 0; br.cnt = 0;
 				refill(S, br);
-				const uint32_t v = getbits(br, 3);
-				if (tid == 0) S.lens[c_clorder[i]] = (uint8_t)v;
+				getbits(br, (int)(f1b & 31u));
 			}
 			__syncthreads();
 			PROF_T(P_T_CLLENS);
