@@ -31,6 +31,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_W
 find $O/pmc_sq -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/pmc_sq_counter_collection.csv
 rm -rf $O/pmc_sq
 timeout -k 10 200 python tools/prof_encode.py --paths 1,2 --reps 30 > $O/prof_encode.log 2>&1
+# every stage alone (serial calls, nothing else on the device), and the INFLATE kernel's phase profile for both geometries
+timeout -k 10 200 python tools/prof_codec.py --reps 5 > $O/prof_codec.log 2>&1
+CCT_INF_PROF=1 timeout -k 10 200 python tools/prof_codec.py --reps 1 --what dec 2>&1 | grep "inflate prof" | head -1 >> $O/prof_codec.log
 echo "pmc done"
 python -c "
 import json
