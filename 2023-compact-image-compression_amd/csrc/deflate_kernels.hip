@@ -119,7 +119,10 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// A tile = 4096 elements: wave w owns elements [t0 + 256 w, t0 + 256 w + 256) and ranks them in four rounds of
 	// 64 (running per-digit counts in its own LDS row), so the cross-wave prefix and its two barriers are paid
 	// once per 4096 elements.  Loads of the next tile are issued before the current one is ranked.
-	constexpr int E = 4;
+#ifndef CCT_SORT_E
+#define CCT_SORT_E 4
+#endif
+	constexpr int E = CCT_SORT_E;
 	auto fetch = [&](uint32_t idx, uint32_t &h, uint32_t &p) {
 		h = 0; p = idx;
 		if (idx < npos) {
