@@ -687,6 +687,11 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 	return CCT_OK;
 }
 
+// Payload bytes one DEFLATE pass takes (its workspaces need 40 bytes per payload byte: 43 GB at this bound, of 288).  2^28
+// in round 1; at 1024x1024 that made passes of 127 slices, and the kernels that give a slice one workgroup (both sort
+// passes, the run list, the block walk) left half of the 256 CUs idle.
+constexpr size_t DEFLATE_PASS_BYTES = (size_t)1 << 30;
+
 // DEFLATE (zlib level 9 stream) of n device-resident byte strings on the device; output slice i =
 // 13 header bytes + zlib stream at d_out + i*out_stride (E.z_out), sizes in E.z_outsizes.
 int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint32_t *d_in_sizes, int n, const uint8_t header13[13],
@@ -1227,7 +1232,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	// With DEFLATE on the device and the whole batch in one pass the host does not need sizes or status before
 	// the DEFLATE kernels are queued (they read the sizes on the device; a payload cannot outgrow its stride):
 	// one host synchronisation less per batch.
-	const bool one_pass = defl && g_ctx.device_deflate && (size_t)n * stride <= ((size_t)1 << 28);
+	const bool one_pass = defl && g_ctx.device_deflate && (size_t)n * stride <= DEFLATE_PASS_BYTES;
 	if (!one_pass) {
 		HIP_TRY(hipStreamSynchronize(E.stream));
 		drain.disarm();
@@ -1241,8 +1246,11 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			for (int i = 0; i < n; i++)
 				if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
 		const size_t zstride = cct_file_bound(width, height, block_size);
-		// bounded workspaces: at most 2^28 payload bytes per pass (the corpus config is 3954 slices)
-		const int chunk = (int)std::max<size_t>(1, ((size_t)1 << 28) / stride);
+		// bounded workspaces: at most DEFLATE_PASS_BYTES of payload per pass, in passes of equal size (several DEFLATE
+		// kernels give a slice one workgroup: a short last pass would leave most of the chip idle)
+		const int chunk_max = (int)std::max<size_t>(1, DEFLATE_PASS_BYTES / stride);
+		const int n_passes = (n + chunk_max - 1) / chunk_max;
+		const int chunk = (n + n_passes - 1) / n_passes;
 		tl_deflate_ms = 0; tl_d2h_ms = 0;
 		struct CopyGuard {  // an error return must not leave a copy into the caller's archive in flight
 			EncSlot &E; bool armed = false;
