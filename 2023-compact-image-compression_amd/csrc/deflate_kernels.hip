@@ -123,23 +123,38 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 #define CCT_SORT_E 4
 #endif
 	constexpr int E = CCT_SORT_E;
-	auto fetch = [&](uint32_t idx, uint32_t &h, uint32_t &p) {
-		h = 0; p = idx;
-		if (idx < npos) {
-			if (FIRST) h = (((uint32_t)in[idx] << 10) ^ ((uint32_t)in[idx + 1] << 5) ^ in[idx + 2]) & 0x7FFFu;
-			else { const uint64_t r = rec_src[idx]; h = (uint32_t)(r >> 32); p = (uint32_t)r; }
-		}
+	// Loads of the next tile are issued before the current one is ranked and taken after it.  Two things the compiler did with
+	// the obvious code: inside a conditional it waits for every load right where it is issued (s_waitcnt vmcnt(0) before the
+	// join), which made the "prefetch" four full memory round trips in a row per tile; and it moved the first use of the
+	// loaded values past this tile's scattered stores, where waiting for the loads means waiting for the stores too (one
+	// in-order counter).  So: the index is clamped instead of tested, the raw values pass through an empty asm right before
+	// the stores (that is where the wait lands), and hash / position are derived after it.
+	const uint32_t last = npos ? npos - 1 : 0;
+	auto fetch = [&](uint32_t idx, uint32_t &ra, uint32_t &rb) {
+		const uint32_t j = min(idx, last);
+		if (FIRST) { uint16_t w; __builtin_memcpy(&w, in + j, 2); ra = w; rb = in[j + 2]; }  // the values as loaded: anything computed here is computed (and waited for) early
+		else { const uint64_t r = rec_src[j]; ra = (uint32_t)r; rb = (uint32_t)(r >> 32); }
+	};
+	auto finish = [&](uint32_t idx, uint32_t ra, uint32_t rb, uint32_t &h, uint32_t &p) {
+		if (FIRST) { h = (((ra & 255u) << 10) ^ ((ra >> 8) << 5) ^ rb) & 0x7FFFu; p = idx; }
+		else { h = rb; p = ra; }
+		if (idx >= npos) { h = 0; p = idx; }
 	};
 	uint32_t hn[E], pn[E];
+	{
+		uint32_t ra[E], rb[E];
 #pragma unroll
-	for (int e = 0; e < E; e++) fetch((uint32_t)(wave * 64 * E + e * 64 + lane), hn[e], pn[e]);
+		for (int e = 0; e < E; e++) fetch((uint32_t)(wave * 64 * E + e * 64 + lane), ra[e], rb[e]);
+#pragma unroll
+		for (int e = 0; e < E; e++) finish((uint32_t)(wave * 64 * E + e * 64 + lane), ra[e], rb[e], hn[e], pn[e]);
+	}
 	for (uint32_t t0 = 0; t0 < npos; t0 += 1024 * E) {
-		uint32_t h[E], p[E], rk[E];
+		uint32_t h[E], p[E], rk[E], ra[E], rb[E];
 		const uint32_t idx0 = t0 + (uint32_t)(wave * 64 * E + lane);
 #pragma unroll
 		for (int e = 0; e < E; e++) { h[e] = hn[e]; p[e] = pn[e]; }
 #pragma unroll
-		for (int e = 0; e < E; e++) fetch(idx0 + 1024 * E + e * 64, hn[e], pn[e]);
+		for (int e = 0; e < E; e++) fetch(idx0 + 1024 * E + e * 64, ra[e], rb[e]);
 		for (int k = lane; k < NB; k += 64) wcnt[wave][k] = 0;
 #pragma unroll
 		for (int e = 0; e < E; e++) {
@@ -171,6 +186,10 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			offs[tid] = run;
 		}
 		lds_barrier();
+#pragma unroll
+		for (int e = 0; e < E; e++) asm volatile("" : "+v"(ra[e]), "+v"(rb[e]) :: "memory");
+#pragma unroll
+		for (int e = 0; e < E; e++) finish(idx0 + 1024 * E + e * 64, ra[e], rb[e], hn[e], pn[e]);
 #pragma unroll
 		for (int e = 0; e < E; e++) {
 			if (idx0 + e * 64 < npos) {
@@ -623,16 +642,21 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 
 // ------------------------------------------------------------------ 3a. decision records + block summaries
 // rec32: bits 0..7 k (deferred literals), 8..16 match length (0 = none), 17..31 distance
-__device__ __forceinline__ void match_at(const MatchRec *mr, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
+__device__ __forceinline__ void match_of(const MatchRec &r, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
 {
-	// deflate_slow: match_length after longest_match + TOO_FAR rule, given prev_length (deflate.c:1863-1880)
+	// deflate_slow: match_length after longest_match + TOO_FAR rule, given prev_length (deflate.c:1863-1880); r = record of p
 	len = 2; dist = 0;
 	if (p >= npos || prev_len >= MAX_MATCH) return;
-	const MatchRec r = mr[p];
 	const int l = prev_len >= 32 ? r.len1024 : r.len4096;
 	const int d = prev_len >= 32 ? r.dist1024 : r.dist4096;
 	if (l > prev_len && l >= MIN_MATCH) { len = l; dist = d; }
 	if (len == MIN_MATCH && dist > TOO_FAR) len = 2;
+}
+__device__ __forceinline__ void match_at(const MatchRec *mr, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
+{
+	len = 2; dist = 0;
+	if (p >= npos || prev_len >= MAX_MATCH) return;
+	match_of(mr[p], p, npos, prev_len, len, dist);
 }
 
 __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
@@ -648,15 +672,20 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 		const uint32_t p = wb * 64 + lane;
 		const uint32_t blk_end = wb * 64 + 64;
 		uint32_t rec = 0, nxt = blk_end, cnt = 0;
+		// the lane's own record and its right neighbour's (what the first deferral test reads) are requested together and
+		// without a branch: a load inside a conditional is waited for on the spot, which made them two round trips in a row
+		const uint32_t lastp = npos ? npos - 1 : 0;
+		const MatchRec r0 = mr[min(p, lastp)], r1 = mr[min(p + 1, lastp)];
 		if (p < L) {
 			int len, dist;
-			match_at(mr, p, npos, 2, len, dist);
+			match_of(r0, p, npos, 2, len, dist);
 			if (len < MIN_MATCH) { rec = 0; nxt = p + 1; cnt = 1; }  // literal in[p]
 			else {
 				uint32_t k = 0;
 				for (;;) {  // lazy evaluation: defer while the next position has a longer match
 					int l2, d2;
-					match_at(mr, p + k + 1, npos, len, l2, d2);
+					if (k == 0) match_of(r1, p + 1, npos, len, l2, d2);
+					else match_at(mr, p + k + 1, npos, len, l2, d2);
 					if (l2 > len) { len = l2; dist = d2; k++; } else break;
 				}
 				rec = k | ((uint32_t)len << 8) | ((uint32_t)dist << 17);
@@ -747,10 +776,16 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 	uint32_t *sym = a.sym + base;
 	uint32_t *bend = a.blk_end + (size_t)s * a.max_blocks;
 	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
-		const uint32_t entry = a.blk_entry[bbase + wb];
-		if (entry == 0xFFFFFFFFu) continue;  // block jumped over by a match
+		// everything the block needs is requested up front and without a branch (a load inside a conditional is waited for on the
+		// spot: entry, record, symbol base and the literal byte used to be four round trips in a row)
 		const uint32_t p = wb * 64 + lane;
-		const uint32_t rec = (p < L) ? a.rec32[base + p] : 0;
+		const uint32_t pc = min(p, L - 1);  // L > 0: nblk64 > 0
+		const uint32_t entry = a.blk_entry[bbase + wb];
+		const uint32_t symbase = a.blk_symbase[bbase + wb];
+		uint32_t rec = a.rec32[base + pc];
+		const uint8_t lit0 = in[pc];
+		if (entry == 0xFFFFFFFFu) continue;  // block jumped over by a match
+		if (p >= L) rec = 0;
 		const uint32_t k = rec & 0xFFu, len = (rec >> 8) & 0x1FFu, dist = rec >> 17;
 		const uint32_t nxt = len ? p + k + len : p + 1;
 		const uint32_t cnt = len ? k + 1 : 1;
@@ -777,11 +812,11 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 			const uint32_t t = __shfl_up(inc, d);
 			if (lane >= d) inc += t;
 		}
-		uint32_t off = a.blk_symbase[bbase + wb] + inc - v;
+		uint32_t off = symbase + inc - v;
 		if (mine) {
 			if (p == L - 1) a.postloop_lit[s] = 1;  // the literal tallied after deflate_slow's main loop
 			for (uint32_t t = 0; t < (len ? k : 1u); t++, off++) {  // literals
-				sym[off] = in[p + t];
+				sym[off] = t ? in[p + t] : lit0;
 				if (off % BLOCK_SYMS == BLOCK_SYMS - 1) bend[off / BLOCK_SYMS] = p + t + 1;
 			}
 			if (len) {
@@ -1526,12 +1561,17 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 	if (threadIdx.x == 0) s_run = bit;
 	for (int i = threadIdx.x; i < 400; i += blockDim.x) wbuf[i] = 0;
 	__syncthreads();
+	// the symbols of the next 256 are requested before these are coded (index clamped, not tested: a load inside a
+	// conditional is waited for on the spot)
+	const uint32_t last_sym = bm.nsym ? bm.nsym - 1 : 0;
+	uint32_t vnext = sym[min((uint32_t)threadIdx.x, last_sym)];
 	for (uint32_t base = 0; base <= bm.nsym; base += blockDim.x) {  // one extra slot for END_BLOCK
 		const uint32_t i = base + threadIdx.x;
 		uint64_t bits = 0;
 		int nb = 0;
+		const uint32_t v = vnext;
+		vnext = sym[min(i + blockDim.x, last_sym)];
 		if (i < bm.nsym) {
-			const uint32_t v = sym[i];
 			uint32_t dist = v >> 16;
 			const uint32_t lc = v & 0xFFu;
 			if (dist == 0) {
