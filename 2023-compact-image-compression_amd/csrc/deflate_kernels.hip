@@ -1297,11 +1297,23 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		for (int i = lane; i < 2 * BL_CODES + 1; i += 64) { S.bfreq[i] = 0; S.blen[i] = 0; S.bdad[i] = 0; }
 		for (int i = lane; i < BL_CODES + 1; i += 64) S.bcode[i] = 0;
 		uint8_t *length_code = S.length_code(), *dist_code = S.dist_code();
-		for (int i = lane; i < 512; i += 64) dist_code[i] = c_dist_code[i];
-		for (int i = lane; i < 256; i += 64) length_code[i] = c_length_code[i];
-		if (lane < 29) S.extra_l[lane] = c_extra_lbits[lane];
-		if (lane < 30) S.extra_d[lane] = c_extra_dbits[lane];
-		if (lane < 19) { S.extra_bl[lane] = c_extra_blbits[lane]; S.bl_order[lane] = c_bl_order[lane]; }
+		{  // the constant tables, all loads first: one round trip instead of sixteen in a row (a per-lane index into
+			// __constant__ memory is a global load, and a load feeding an LDS store in a rolled loop is waited for at once)
+			uint8_t dc[8], lc4[4];
+#pragma unroll
+			for (int k = 0; k < 8; k++) dc[k] = c_dist_code[lane + 64 * k];
+#pragma unroll
+			for (int k = 0; k < 4; k++) lc4[k] = c_length_code[lane + 64 * k];
+			const int l29 = min(lane, 28), l30 = min(lane, 29), l19 = min(lane, 18);
+			const uint8_t xl = c_extra_lbits[l29], xd = c_extra_dbits[l30], xb = c_extra_blbits[l19], bo = c_bl_order[l19];
+#pragma unroll
+			for (int k = 0; k < 8; k++) dist_code[lane + 64 * k] = dc[k];
+#pragma unroll
+			for (int k = 0; k < 4; k++) length_code[lane + 64 * k] = lc4[k];
+			if (lane < 29) S.extra_l[lane] = xl;
+			if (lane < 30) S.extra_d[lane] = xd;
+			if (lane < 19) { S.extra_bl[lane] = xb; S.bl_order[lane] = bo; }
+		}
 		uint32_t *hl = S.hist_l(), *hd = S.hist_d();
 		for (int i = lane; i < L_CODES; i += 64) hl[i] = 0;
 		if (lane < D_CODES) hd[lane] = 0;
@@ -1542,22 +1554,30 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(DeflateArgs a)
 	__shared__ uint16_t t_lcode[L_CODES + 2], t_dcode[D_CODES + 2];
 	__shared__ uint8_t t_llen[L_CODES + 2], t_dlen[D_CODES + 2];
 	__shared__ uint32_t wbuf[400];  // 256 symbols x <= 48 bits = 384 words, + alignment word
-	for (int i = threadIdx.x; i < L_CODES; i += blockDim.x) {
-		t_lcode[i] = dyn ? bt->lcode[i] : c_static_lcode[i];
-		t_llen[i] = dyn ? bt->llen[i] : c_static_llen[i];
-	}
-	if (threadIdx.x < D_CODES) {
-		t_dcode[threadIdx.x] = dyn ? bt->dcode[threadIdx.x] : c_static_dcode[threadIdx.x];
-		t_dlen[threadIdx.x] = dyn ? bt->dlen[threadIdx.x] : (uint8_t)5;
-	}
 	// the symbol -> code tables of trees.c, staged in LDS: a __constant__ lookup with a per-lane index is a global
 	// load, and every iteration with a match in it would wait for four of them in a row
 	__shared__ uint8_t t_length_code[256], t_dist_code[512], t_extra_l[32], t_extra_d[32];
 	__shared__ uint16_t t_base_length[32], t_base_dist[32];
-	for (int i = threadIdx.x; i < 512; i += blockDim.x) t_dist_code[i] = c_dist_code[i];
-	t_length_code[threadIdx.x] = c_length_code[threadIdx.x];  // blockDim.x == 256
-	if (threadIdx.x < 29) { t_extra_l[threadIdx.x] = c_extra_lbits[threadIdx.x]; t_base_length[threadIdx.x] = c_base_length[threadIdx.x]; }
-	if (threadIdx.x < 30) { t_extra_d[threadIdx.x] = c_extra_dbits[threadIdx.x]; t_base_dist[threadIdx.x] = c_base_dist[threadIdx.x]; }
+	{  // every table entry this lane stages is requested before the first is stored (clamped indices, no branches around the
+		// loads): one memory round trip instead of a dozen in a row.  blockDim.x == 256
+		const int t = threadIdx.x, t2 = min(t + 256, L_CODES - 1), td = min(t, D_CODES - 1), t29 = min(t, 28), t30 = min(t, 29);
+		const uint16_t *lsrc = dyn ? bt->lcode : c_static_lcode, *dsrc = dyn ? bt->dcode : c_static_dcode;
+		const uint8_t *llsrc = dyn ? bt->llen : c_static_llen;
+		const uint16_t lc0 = lsrc[t], lc1 = lsrc[t2];
+		const uint8_t ll0 = llsrc[t], ll1 = llsrc[t2];
+		const uint16_t dc = dsrc[td];
+		uint8_t dl = bt->dlen[td];
+		if (!dyn) dl = 5;
+		const uint8_t k0 = c_dist_code[t], k1 = c_dist_code[t + 256], lcd = c_length_code[t];
+		const uint8_t xl = c_extra_lbits[t29], xd = c_extra_dbits[t30];
+		const uint16_t bl = c_base_length[t29], bd = c_base_dist[t30];
+		t_lcode[t] = lc0; t_llen[t] = ll0;
+		if (t + 256 < L_CODES) { t_lcode[t + 256] = lc1; t_llen[t + 256] = ll1; }
+		if (t < D_CODES) { t_dcode[t] = dc; t_dlen[t] = dl; }
+		t_dist_code[t] = k0; t_dist_code[t + 256] = k1; t_length_code[t] = lcd;
+		if (t < 29) { t_extra_l[t] = xl; t_base_length[t] = bl; }
+		if (t < 30) { t_extra_d[t] = xd; t_base_dist[t] = bd; }
+	}
 	if (threadIdx.x == 0) s_run = bit;
 	for (int i = threadIdx.x; i < 400; i += blockDim.x) wbuf[i] = 0;
 	__syncthreads();
