@@ -501,19 +501,24 @@ __global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
 	uint32_t *rs = re + (a.in_stride >> 2);
 	uint32_t *rl = re + (a.in_stride >> 1);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	auto load8 = [&](int64_t x) -> uint64_t {  // bytes in[x .. x+7], zero outside [0, L)
-		uint64_t w = 0;
-		if (x >= 0 && x + 8 <= (int64_t)L) __builtin_memcpy(&w, in + x, 8);
-		else for (int k = 0; k < 8; k++) { const int64_t y = x + k; if (y >= 0 && y < (int64_t)L) w |= (uint64_t)in[y] << (8 * k); }
-		return w;
+	// bytes in[x .. x+7] for x a multiple of 8, zero outside [0, L): one aligned load from a clamped address, masked afterwards
+	// (no branch around the load: the three words of a lane are in flight together, and the next chunk's are requested before
+	// this chunk's lists are written)
+	const int64_t xmax = (int64_t)a.in_stride - 8;
+	auto load8 = [&](int64_t x) -> uint64_t { return *reinterpret_cast<const uint64_t *>(in + min(max(x, (int64_t)0), xmax)); };
+	auto clip8 = [&](uint64_t w, int64_t x) -> uint64_t {
+		if (x < 0 || x >= (int64_t)L) return 0ull;
+		return x + 8 > (int64_t)L ? w & ((1ull << (8 * ((int64_t)L - x))) - 1ull) : w;
 	};
 	uint32_t base_e = 0, base_s = 0;
 	int par = 0;
+	uint64_t np = load8((int64_t)tid * 8 - 8), nc = load8((int64_t)tid * 8), nn = load8((int64_t)tid * 8 + 8);
 	for (uint32_t c0 = 0; c0 < L; c0 += 8192, par ^= 1) {
 		const uint32_t x0 = c0 + (uint32_t)tid * 8;
 		uint32_t me = 0, ms = 0;
+		const uint64_t wp = clip8(np, (int64_t)x0 - 8), wc = clip8(nc, x0), wn = clip8(nn, (int64_t)x0 + 8);
+		np = load8((int64_t)x0 + 8192 - 8); nc = load8((int64_t)x0 + 8192); nn = load8((int64_t)x0 + 8192 + 8);
 		if (x0 < L) {
-			const uint64_t wp = load8((int64_t)x0 - 8), wc = load8(x0), wn = load8((int64_t)x0 + 8);
 			auto bt = [&](int i) -> uint32_t {  // in[x0 + i], i in [-3, 9]
 				return i < 0 ? (uint32_t)(wp >> (8 * (i + 8))) & 0xFFu : i < 8 ? (uint32_t)(wc >> (8 * i)) & 0xFFu : (uint32_t)(wn >> (8 * (i - 8))) & 0xFFu;
 			};
@@ -540,6 +545,7 @@ __global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
 			if (w2 < wave) { ie += te; is += ts; }
 			base_e += te; base_s += ts;
 		}
+		asm volatile("" : "+v"(np), "+v"(nc), "+v"(nn) :: "memory");  // taken before the stores below: see dfl_sort_pass_kernel
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
 			if ((me >> k) & 1u) re[ie++] = x0 + k;
