@@ -381,7 +381,10 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 			t.tiles.geom[to * 2 + half] = geom;
 		}
 	if (nt > 256) return;
-	for (int ti = 0; ti < nt; ti++) { t.tiles.org[ti] = org[ti]; t.tiles.orient[ti] = orient[ti]; }
+	for (int ti = 0; ti < nt; ti++) {
+		if (org[ti] >= (1u << 24)) return;
+		t.tiles.orgo[ti] = org[ti] | ((uint32_t)orient[ti] << 24);
+	}
 	for (int to = 0; to < no; to++) { t.tiles.last[to] = tile_last[to]; t.tiles.mid[to] = tile_mid[to]; }
 	std::vector<uint32_t> otab(64, 0);
 	for (size_t bo = 0; bo < bpat.size(); bo++) {

@@ -54,8 +54,8 @@ constexpr int PIPE_DEFAULT_MAX_NB = 16384;  // largest slice for which the pipel
 constexpr int PIPE_PAIR_REC = 80;           // bytes per meshed-pair record: jump byte + up to 64 token bytes, padded to 16
 constexpr uint32_t CCT_ST_INTERNAL = 0x80000000u;  // the kernels disagree about a size: a bug, never a data property
 struct PipeTiles {             // small per-shape tables carried IN the kernel arguments: one scalar load, no pointer to chase
-	uint32_t org[256];           // raster index of each tile's top-left pixel
-	uint8_t orient[256];         // tile orientation
+	uint32_t orgo[256];          // raster index of each tile's top-left pixel (< 2^24) | tile orientation << 24: ONE scalar load gives
+	                             // both (a byte array indexed by the tile became a vector load the next table lookup had to wait for)
 	uint32_t last[TILE_MAX_ORIENT];  // raster offset inside the tile of the tile's last traversal position
 	uint32_t mid[TILE_MAX_ORIENT];   // the same for position 2047 (the last pixel of the first half tile)
 	uint32_t geom[TILE_MAX_ORIENT * 2];  // region of half h of orientation o: bit 0 = vertical split (32x64 pixels), bits 8.. = first

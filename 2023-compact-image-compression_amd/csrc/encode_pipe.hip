@@ -35,6 +35,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define LDS(T) __attribute__((address_space(3))) T
 
 constexpr int PW = 128;             // lanes per workgroup of K1 / K3: one 64x64 tile, a pair of blocks per lane
+#define TILE_ORG(a, t) ((a).tiles.orgo[t] & 0xFFFFFFu)
+#define TILE_ORIENT(a, t) ((int)((a).tiles.orgo[t] >> 24))
 
 // ---- packed 16-bit arithmetic (two pixels per instruction) --------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -219,20 +221,20 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 	const int by = tid >> 3, bxp = tid & 7;
 	const size_t reg_off = (size_t)(by * 4) * pitch + bxp * 8;
 	auto load_rows = [&](int tile, u32x4 r[4]) {
-		const uint16_t *p = img + a.tiles.org[tile] + reg_off;
+		const uint16_t *p = img + TILE_ORG(a, tile) + reg_off;
 #pragma unroll
 		for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
 	};
 	// pixels before the lane's two blocks (traversal order); a block that opens its tile follows the previous tile's last pixel
 	auto load_prev = [&](int tile, const u32x4 &ent, uint32_t &pa, uint32_t &pb) {
-		const uint32_t org = a.tiles.org[tile];
-		const uint32_t porg = tile > 0 ? a.tiles.org[tile - 1] + a.tiles.last[a.tiles.orient[tile - 1]] : 0u;
+		const uint32_t org = TILE_ORG(a, tile);
+		const uint32_t porg = tile > 0 ? TILE_ORG(a, tile - 1) + a.tiles.last[TILE_ORIENT(a, tile - 1)] : 0u;
 		pa = img[ent.y != 0xFFFFFFFFu ? org + ent.y : porg];
 		pb = img[ent.z != 0xFFFFFFFFu ? org + ent.z : porg];
 	};
 	u32x4 r[4], ent;
 	load_rows(t0, r);
-	ent = ptab[(int)a.tiles.orient[t0] * PW + tid];
+	ent = ptab[TILE_ORIENT(a, t0) * PW + tid];
 	if (tid < 64) otab[tid] = a.otab[tid];
 	uint32_t pvA, pvB;
 	load_prev(t0, ent, pvA, pvB);
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(PW) pipe_analyse_kernel(PipeArgs a, int tpw, u
 		const uint32_t cpA = pvA, cpB = pvB;
 		if (s + 1 < nT) {  // the next tile's rows are in flight across the analysis below
 			load_rows(tile + 1, r);
-			ent = ptab[(int)a.tiles.orient[tile + 1] * PW + tid];
+			ent = ptab[TILE_ORIENT(a, tile + 1) * PW + tid];
 		}
 		stamp<STAMP>(st, 1);
 		uint32_t orall = cpA | cpB;
@@ -321,8 +323,8 @@ __global__ void __launch_bounds__(64 * MW) pipe_masks_kernel(PipeArgs a, uint64_
 	for (int ti = q; ti < ntl; ti += MQ) {
 	const int tile = (int)a.tlist[(size_t)sl * NT + ti];  // 32-bit entries: a wave-uniform read becomes a scalar (dword-aligned) load
 	const bool has_next = tile + 1 < NT;
-	const int to0 = a.tiles.orient[tile], to1 = has_next ? a.tiles.orient[tile + 1] : to0;
-	const uint32_t org0 = a.tiles.org[tile], org1 = has_next ? a.tiles.org[tile + 1] : org0;
+	const int to0 = TILE_ORIENT(a, tile), to1 = has_next ? TILE_ORIENT(a, tile + 1) : to0;
+	const uint32_t org0 = TILE_ORG(a, tile), org1 = has_next ? TILE_ORG(a, tile + 1) : org0;
 	// ---- this lane's block of the tile (and, for the first wave, of the next tile's first quarter)
 	// lanes 0..255: the tile's blocks; lanes 256..319: the next tile's first 64 blocks; the rest idle here
 	const bool own = tid < 256, nxt = tid >= 256 && tid < 320 && has_next;
@@ -795,22 +797,24 @@ __global__ void __launch_bounds__(64) pipe_pack_kernel(PipeArgs a, uint64_t *sta
 	const int hb = ht * 128;  // first block of the half tile in the slice
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 	const int pitch = a.row_pitch;
-	const int to = a.tiles.orient[tile];
+	const int to = TILE_ORIENT(a, tile);
 
 	// ---- every global load, issued together
 	const u32x4 ent = reinterpret_cast<const u32x4 *>(a.ptab2)[(to * 2 + half) * 64 + lane];
-	const uint32_t org = a.tiles.org[tile];
+	const uint32_t org = TILE_ORG(a, tile);
 	uint32_t before_addr = 0;  // the pixel before the half tile (none: the slice starts from pixel value 0, core.py:278)
 	if (half) before_addr = org + a.tiles.mid[to];
-	else if (tile > 0) before_addr = a.tiles.org[tile - 1] + a.tiles.last[a.tiles.orient[tile - 1]];
+	else if (tile > 0) before_addr = TILE_ORG(a, tile - 1) + a.tiles.last[TILE_ORIENT(a, tile - 1)];
 	const uint32_t *toff = a.toff + (size_t)sl * (NH + 1);
 	const uint32_t off_t = toff[ht], off_n = toff[ht + 1];
 	const uint8_t *roles = a.roles + (size_t)sl * NB + hb;
 	const uint32_t *spec = a.spec + (size_t)sl * NB + hb;
 	const uint32_t role2 = *reinterpret_cast<const uint16_t *>(roles + 2 * lane);
 	const uint2 spec2 = *reinterpret_cast<const uint2 *>(spec + 2 * lane);
-	uint32_t edge = 0;  // lane 0: role of the block before the half tile | pixel before the half tile << 16
-	if (lane == 0) edge = (hb > 0 ? (uint32_t)roles[-1] : 0u) | (ht > 0 ? (uint32_t)img[before_addr] << 16 : 0u);
+	// lane 0: role of the block before the half tile | pixel before the half tile << 16.  Read by every lane (one address, one
+	// transaction) from a clamped address: a load under `if (lane == 0)` is waited for on the spot, before the rows are requested
+	const uint32_t edge_role = roles[hb > 0 ? -1 : 0], edge_px = img[before_addr];
+	const uint32_t edge = (hb > 0 ? edge_role : 0u) | (ht > 0 ? edge_px << 16 : 0u);
 	const uint32_t geom = a.tiles.geom[to * 2 + half];
 	const uint32_t reg_off = (geom & 1u) ? (uint32_t)((lane >> 2) * 4 * pitch) + ((geom >> 8) + (uint32_t)(lane & 3)) * 8u
 	                                     : ((geom >> 8) + (uint32_t)(lane >> 3)) * 4u * (uint32_t)pitch + (uint32_t)(lane & 7) * 8u;
