@@ -160,7 +160,7 @@ def main():
                     help="skip the short run with the other --encode-slots setting after the timed region (use under a tracer)")
     ap.add_argument("--encode-slots", type=int, default=1, choices=(1, 2),
                     help="encode batches on the device at a time (library option encode_slots; 2 is worth -8 ... +8 %% end to end at 512x512 "
-                         "depending on the box and +8 %% at 1024x1024, but then every kernel's duration includes another batch's "
+                         "depending on the box and +6 %% at 1024x1024, but then every kernel's duration includes another batch's "
                          "DEFLATE pass next to it)")
     args = ap.parse_args()
     edge, n = WORKLOADS[args.config]
