@@ -396,7 +396,11 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 				r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
 				r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
 			}
+#ifdef CCT_MATCH_PROBE  // tuning builds only (results invalid): what the scattered result store / the own-string load cost
+			if (CCT_MATCH_PROBE != 1) mr[p] = r; else if (r.len4096 == 0xFFFE) mr[p] = r;
+#else
 			mr[p] = r;
+#endif
 		}
 		// wave-aggregated appends: one atomic per wave and list
 		const uint64_t bh = __ballot(kind == 1), br = __ballot(kind == 2);
