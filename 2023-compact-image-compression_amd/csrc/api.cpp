@@ -169,6 +169,10 @@ double now_ms()
 }
 
 Context g_ctx;
+}  // namespace
+std::shared_mutex g_quiesce;
+thread_local int tl_api_depth = 0;
+namespace {
 int inflate_lanes_now()
 {
 	const int lanes = g_ctx.inflate_lanes ? g_ctx.inflate_lanes : (g_encodes_in_flight.load(std::memory_order_relaxed) > 0 ? 256 : 512);
@@ -647,8 +651,11 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 				if (E.p_graphs.size() >= 6) {  // forget the least recently used argument set
 					size_t old = 0;
 					for (size_t i = 1; i < E.p_graphs.size(); i++) if (E.p_graphs[i].last_use < E.p_graphs[old].last_use) old = i;
-					if (E.p_graphs[old].exec) (void)hipGraphExecDestroy(E.p_graphs[old].exec);
-					if (E.p_graphs[old].graph) (void)hipGraphDestroy(E.p_graphs[old].graph);
+					exclusive_section([&]() -> int {
+						if (E.p_graphs[old].exec) (void)hipGraphExecDestroy(E.p_graphs[old].exec);
+						if (E.p_graphs[old].graph) (void)hipGraphDestroy(E.p_graphs[old].graph);
+						return 0;
+					});
 					E.p_graphs.erase(E.p_graphs.begin() + (long)old);
 				}
 				E.p_graphs.emplace_back();
@@ -659,12 +666,16 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 			}
 			pg->last_use = ++E.p_clock;
 			if (!pg->exec) {
-				HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-				hipError_t le = launch_encode_pipe(pa, n, st, &tune);
-				hipError_t ce = hipStreamEndCapture(st, &pg->graph);
-				if (le != hipSuccess) return fail(CCT_E_DEVICE, "pipeline capture: %s", hipGetErrorString(le));
-				HIP_TRY(ce);
-				HIP_TRY(hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0));
+				const int crc = exclusive_section([&]() -> int {  // nothing else of the library runs during a capture (host.h)
+					HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+					hipError_t le = launch_encode_pipe(pa, n, st, &tune);
+					hipError_t ce = hipStreamEndCapture(st, &pg->graph);
+					if (le != hipSuccess) return fail(CCT_E_DEVICE, "pipeline capture: %s", hipGetErrorString(le));
+					HIP_TRY(ce);
+					HIP_TRY(hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0));
+					return CCT_OK;
+				});
+				if (crc) return crc;
 			}
 			HIP_TRY(hipGraphLaunch(pg->exec, st));
 			return CCT_OK;
@@ -746,14 +757,18 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
 		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
 		if (!E.z_graph_exec || key != E.z_graph_key) {
-			if (E.z_graph_exec) { (void)hipGraphExecDestroy(E.z_graph_exec); E.z_graph_exec = nullptr; }
-			if (E.z_graph) { (void)hipGraphDestroy(E.z_graph); E.z_graph = nullptr; }
-			HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
-			hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream);
-			hipError_t ce = hipStreamEndCapture(E.stream, &E.z_graph);
-			if (le != hipSuccess) return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le));
-			HIP_TRY(ce);
-			HIP_TRY(hipGraphInstantiate(&E.z_graph_exec, E.z_graph, nullptr, nullptr, 0));
+			const int crc = exclusive_section([&]() -> int {  // nothing else of the library runs during a capture (host.h)
+				if (E.z_graph_exec) { (void)hipGraphExecDestroy(E.z_graph_exec); E.z_graph_exec = nullptr; }
+				if (E.z_graph) { (void)hipGraphDestroy(E.z_graph); E.z_graph = nullptr; }
+				HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
+				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream);
+				hipError_t ce = hipStreamEndCapture(E.stream, &E.z_graph);
+				if (le != hipSuccess) return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le));
+				HIP_TRY(ce);
+				HIP_TRY(hipGraphInstantiate(&E.z_graph_exec, E.z_graph, nullptr, nullptr, 0));
+				return CCT_OK;
+			});
+			if (crc) return crc;
 			E.z_graph_key = key;
 		}
 		HIP_TRY(hipGraphLaunch(E.z_graph_exec, E.stream));
@@ -1017,6 +1032,7 @@ int cct_encode_payload_dev(const uint16_t *d_images, int n, int width, int heigh
                            uint32_t *d_status, cct_slice_stats *d_stats, uint8_t *d_roles)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
+	ApiCall in_call;
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
@@ -1071,12 +1087,16 @@ static int files_to_pinned_archive_async(FilesOut &f, uint8_t *h_dst, std::uniqu
 	int rc;
 	const unsigned slot = E.pack_slot++ & 1u;
 	if (!E.stream_copy) {
-		HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
-		for (int k = 0; k < 2; k++) {
-			HIP_TRY(hipEventCreateWithFlags(&E.ev_pack[k], hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
-			HIP_TRY(hipEventRecord(E.ev_copied[k], E.stream_copy));
-		}
+		const int crc = exclusive_section([&]() -> int {
+			HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
+			for (int k = 0; k < 2; k++) {
+				HIP_TRY(hipEventCreateWithFlags(&E.ev_pack[k], hipEventDisableTiming));
+				HIP_TRY(hipEventCreateWithFlags(&E.ev_copied[k], hipEventDisableTiming));
+				HIP_TRY(hipEventRecord(E.ev_copied[k], E.stream_copy));
+			}
+			return CCT_OK;
+		});
+		if (crc) return crc;
 	}
 	const size_t cap = f.offs[f.nc] + 16;  // the pack kernel works in 16-byte units
 	if (E.z_packed2[slot].cap < cap) HIP_TRY(hipEventSynchronize(E.ev_copied[slot]));  // about to be reallocated
@@ -1196,6 +1216,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	}
 	std::unique_lock<std::mutex> lk;
 	EncSlot &E = acquire_encode_slot(lk);
+	ApiCall in_call;  // after the slot: a thread waiting for a slot must not keep exclusive sections of the others waiting
 	const double t_lock0 = now_ms();
 	if ((rc = ensure_ctx())) return rc;
 	if (n == 0) return CCT_OK;
@@ -1348,6 +1369,7 @@ int cct_zlib_compress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int 
                             uint32_t *h_out_sizes)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
+	ApiCall in_call;
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	int rc = ensure_ctx();
 	if (rc) return rc;
@@ -1402,6 +1424,7 @@ int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, in
 {
 	std::unique_lock<std::mutex> lkd;
 	DecSlot &D = acquire_decode_slot(lkd);
+	ApiCall in_call;
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (out_stride == 0 || (out_stride & 15)) return fail(CCT_E_ARG, "out_stride must be a positive multiple of 16");
 	if (!(g_ctx.ready && g_ctx.pid == getpid())) {
@@ -1472,6 +1495,7 @@ int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, cons
 {
 	std::lock_guard<std::mutex> lkd(g_dec[0].mu);  // the workspaces of decode slot 0, on the main stream
 	std::lock_guard<std::mutex> lk(g_mu);
+	ApiCall in_call;
 	int rc = check_shape(n, width, height, block_size);
 	if (rc) return rc;
 	if ((rc = ensure_ctx())) return rc;
@@ -1484,6 +1508,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 {
 	std::unique_lock<std::mutex> lkd;
 	DecSlot &D = acquire_decode_slot(lkd);
+	ApiCall in_call;
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (n == 0) return CCT_OK;
 	cct_header h0;

@@ -18,6 +18,7 @@ static int packbits_batch(bool encode, const uint8_t *h_in, const uint64_t *h_of
 	if (n < 0 || !h_offsets || (n > 0 && (!h_in || !h_out || !h_out_sizes))) return fail(CCT_E_ARG, "bad argument");
 	if (n == 0) return CCT_OK;
 	std::lock_guard<std::mutex> lk(g_mu);
+	ApiCall in_call;
 	int rc = ensure_ctx();
 	if (rc) return rc;
 	hipStream_t st = main_stream();

@@ -280,15 +280,19 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	__syncthreads();
 	DEC_STAMP();
 
-	auto load_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt, int &nvalid) {
-		w = make_uint4(0, 0, 0, 0);
-		nxt = 0;
-		nvalid = 0;
-		if (seg_start < Lr) {
-			w = *reinterpret_cast<const uint4 *>(P + seg_start);  // stride is a multiple of 256
-			nvalid = (int)min(16u, Lr - seg_start);
-			if (seg_start + 16u < Lr) nxt = P[seg_start + 16u];
-		}
+	// No branch around the loads (the address is clamped, the result selected): a load inside a conditional is waited for on the
+	// spot, which defeats requesting the next step's segment ahead of time.  stride is a multiple of 256 and Lr <= stride, so a
+	// segment that starts inside the payload is read from its own address.
+	const uint32_t seg_max = (uint32_t)a.stride - 16u;
+	auto load_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt) {  // the bytes as loaded: nothing is derived from them here,
+		w = *reinterpret_cast<const uint4 *>(P + min(seg_start, seg_max));  // or the wait lands where the load is issued
+		nxt = P[min(seg_start + 16u, (uint32_t)a.stride - 1u)];
+	};
+	auto clip_seg = [&](uint32_t seg_start, uint4 &w, uint32_t &nxt, int &nvalid) {  // what lies past the payload reads as zero
+		const bool inside = seg_start < Lr;
+		nvalid = inside ? (int)min(16u, Lr - seg_start) : 0;
+		if (!inside) w = make_uint4(0, 0, 0, 0);
+		if (!(seg_start + 16u < Lr)) nxt = 0;
 	};
 	auto jset = [&](uint32_t k, uint32_t ord, uint32_t j) {
 		if (k < DEC_JLIST_CAP) { l_jord[k] = ord; l_jval[k] = (uint8_t)j; }
@@ -300,10 +304,16 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	int32_t val_c = 0;
 	uint2 *pcache = a.ws_pcache + (size_t)s * a.pcache_steps * T;
 	uint32_t nsteps = 0;
+	uint4 wa_n; uint32_t nxta_n;
+	load_seg((uint32_t)tid * DEC_SEG, wa_n, nxta_n);
 	for (uint32_t base = 0; base < Lr && npix_c < (uint32_t)N; base += (uint32_t)T * DEC_SEG, nsteps++) {
-		uint4 w; uint32_t nxt; int nvalid;
-		load_seg(base + (uint32_t)tid * DEC_SEG, w, nxt, nvalid);
+		uint4 w = wa_n; uint32_t nxt = nxta_n; int nvalid;
+		clip_seg(base + (uint32_t)tid * DEC_SEG, w, nxt, nvalid);
+		load_seg(base + (uint32_t)(T + tid) * DEC_SEG, wa_n, nxta_n);  // the next step's segment, in flight across the scans below
 		const Parse p = parse_step(w, nxt, nvalid, scratch, st_c, npix_c, val_c, nj_c);
+		// taken before this step's stores: one in-order counter covers loads and stores, so a wait for the segment placed after
+		// them would wait for them too
+		asm volatile("" : "+v"(wa_n.x), "+v"(wa_n.y), "+v"(wa_n.z), "+v"(wa_n.w), "+v"(nxta_n) :: "memory");
 		pcache[(size_t)nsteps * T + tid] = make_uint2(min(p.pix_base, 0x7FFFFFFFu) | (p.entry << 31), (uint32_t)p.val_base);
 		if (p.st.njump) {
 			const SegMasks sm = seg_masks(w, nvalid);
@@ -397,9 +407,9 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 	if (!(s_status & CCT_ST_STREAM)) {
 		// every lane re-reads its segments and what pass A's scans told it about them: no barrier in this pass; the loads
 		// of the next step are issued before this step's pixels are written
-		uint4 w_n = make_uint4(0, 0, 0, 0); uint32_t nxt_n = 0; int nvalid_n = 0;
-		uint2 pc_n = make_uint2(0, 0);
-		if (nsteps) { load_seg((uint32_t)tid * DEC_SEG, w_n, nxt_n, nvalid_n); pc_n = pcache[tid]; }
+		uint4 w_n; uint32_t nxt_n;
+		load_seg((uint32_t)tid * DEC_SEG, w_n, nxt_n);
+		uint2 pc_n = pcache[tid];  // (slot 0 of the step cache exists even for an empty payload)
 #ifdef CCT_DEC_PROF
 		long long tb[4] = {0, 0, 0, 0}, tq = clock64();
 #define DECB(j) do { const long long t_ = clock64(); tb[j] += t_ - tq; tq = t_; } while (0)
@@ -408,9 +418,11 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 #endif
 		for (uint32_t k = 0; k < nsteps; k++) {
 			const uint32_t seg_start = k * (uint32_t)T * DEC_SEG + (uint32_t)tid * DEC_SEG;
-			const uint4 w = w_n; const uint32_t nxt = nxt_n; const int nvalid = nvalid_n;
+			uint4 w = w_n; uint32_t nxt = nxt_n; int nvalid;
+			clip_seg(seg_start, w, nxt, nvalid);
 			const uint2 pc = pc_n;
-			if (k + 1 < nsteps) { load_seg(seg_start + (uint32_t)T * DEC_SEG, w_n, nxt_n, nvalid_n); pc_n = pcache[(size_t)(k + 1) * T + tid]; }
+			load_seg(seg_start + (uint32_t)T * DEC_SEG, w_n, nxt_n);  // next step (clamped addresses: no branch around the loads)
+			pc_n = pcache[(size_t)min(k + 1, nsteps - 1) * T + tid];
 			Parse p;
 			p.entry = pc.x >> 31; p.pix_base = pc.x & 0x7FFFFFFFu; p.val_base = (int32_t)pc.y;
 			// token structure of the segment as masks (see seg_masks): the loop below visits pixel tokens only

@@ -4,7 +4,9 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
+#include <shared_mutex>
 
 #include <hip/hip_runtime.h>
 
@@ -22,6 +24,33 @@ int fail(int code, const char *fmt, ...);
 			return ::cct::fail(CCT_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
 	} while (0)
 
+// Runtime operations that are rare and heavy -- stream capture and graph instantiation / destruction, device and pinned
+// allocations, stream creation -- never run next to another call of the library: every entry point that drives the device
+// holds `g_quiesce` shared from the moment it owns its slot (ApiCall), and those operations give it up and take it
+// exclusively (exclusive_section).  Order: slot mutex, then g_quiesce; a thread waiting for a slot holds neither.  (Two encode
+// calls, one capturing its graphs for the first time while the other allocated, were seen to hang inside the runtime about
+// once in ten runs of the concurrency test; steady-state launches, copies and synchronisations from several threads never
+// did, over thousands of overlapped steps.)
+extern std::shared_mutex g_quiesce;
+extern thread_local int tl_api_depth;
+struct ApiCall {
+	ApiCall() { if (tl_api_depth++ == 0) g_quiesce.lock_shared(); }
+	~ApiCall() { if (--tl_api_depth == 0) g_quiesce.unlock_shared(); }
+	ApiCall(const ApiCall &) = delete;
+	ApiCall &operator=(const ApiCall &) = delete;
+};
+template <class F>
+auto exclusive_section(F f) -> decltype(f())
+{
+	static const bool off = getenv("CCT_NO_QUIESCE") != nullptr;  // debugging only: the behaviour before this lock existed
+	if (off) return f();
+	const bool shared = tl_api_depth > 0;
+	if (shared) g_quiesce.unlock_shared();
+	g_quiesce.lock();
+	struct Back { bool shared; ~Back() { g_quiesce.unlock(); if (shared) g_quiesce.lock_shared(); } } back{shared};
+	return f();
+}
+
 struct DevBuf {  // grow-only device (or pinned host) buffer
 	void *p = nullptr;
 	size_t cap = 0;
@@ -29,12 +58,14 @@ struct DevBuf {  // grow-only device (or pinned host) buffer
 	int ensure(size_t bytes)
 	{
 		if (bytes <= cap) return CCT_OK;
-		release();
-		const size_t want = bytes + bytes / 8 + 4096;
-		hipError_t e = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-		if (e != hipSuccess) { p = nullptr; cap = 0; return fail(CCT_E_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); }
-		cap = want;
-		return CCT_OK;
+		return exclusive_section([&]() -> int {
+			release();
+			const size_t want = bytes + bytes / 8 + 4096;
+			hipError_t e = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+			if (e != hipSuccess) { p = nullptr; cap = 0; return fail(CCT_E_NOMEM, "allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); }
+			cap = want;
+			return CCT_OK;
+		});
 	}
 	void release()
 	{
