@@ -22,7 +22,9 @@
  * against each other: every host-facing call is complete when it returns (cct_dev_memset
  * and the h2d/d2h copies included); only cct_encode_payload_dev / cct_decode_payload_dev
  * leave work queued (main / decode stream) -- call cct_sync() before another call reads or
- * overwrites their buffers.
+ * overwrites their buffers.  Rare runtime work -- capturing and instantiating a slot's graphs, growing a workspace,
+ * creating a stream -- is done with no other call of the library in flight (the other calls finish first; a
+ * call that arrives meanwhile waits a few milliseconds): this happens on the first batches of a shape only.
  * The library initialises HIP lazily on the first device call.  Processes that fork
  * workers (scripts/evaluate.py:107) must fork BEFORE that call: each child then binds the
  * GPU itself.  A child forked after its parent initialised the GPU gets CCT_E_DEVICE from
