@@ -170,7 +170,7 @@ double now_ms()
 
 Context g_ctx;
 }  // namespace
-std::shared_mutex g_quiesce;
+QuiesceLock g_quiesce;
 thread_local int tl_api_depth = 0;
 namespace {
 int inflate_lanes_now()

@@ -5,8 +5,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <condition_variable>
 #include <mutex>
-#include <shared_mutex>
 
 #include <hip/hip_runtime.h>
 
@@ -31,7 +31,17 @@ int fail(int code, const char *fmt, ...);
 // calls, one capturing its graphs for the first time while the other allocated, were seen to hang inside the runtime about
 // once in ten runs of the concurrency test; steady-state launches, copies and synchronisations from several threads never
 // did, over thousands of overlapped steps.)
-extern std::shared_mutex g_quiesce;
+struct QuiesceLock {  // shared / exclusive with priority for the exclusive side (glibc's rwlock prefers readers: with three
+	std::mutex m;        // threads issuing calls back to back an exclusive section could wait for a long time)
+	std::condition_variable cv;
+	int readers = 0, writers_waiting = 0;
+	bool writer = false;
+	void lock_shared() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !writer && writers_waiting == 0; }); readers++; }
+	void unlock_shared() { std::unique_lock<std::mutex> l(m); if (--readers == 0) cv.notify_all(); }
+	void lock() { std::unique_lock<std::mutex> l(m); writers_waiting++; cv.wait(l, [&] { return !writer && readers == 0; }); writers_waiting--; writer = true; }
+	void unlock() { std::unique_lock<std::mutex> l(m); writer = false; cv.notify_all(); }
+};
+extern QuiesceLock g_quiesce;
 extern thread_local int tl_api_depth;
 struct ApiCall {
 	ApiCall() { if (tl_api_depth++ == 0) g_quiesce.lock_shared(); }
