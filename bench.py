@@ -159,8 +159,8 @@ def main():
     ap.add_argument("--no-slot-comparison", action="store_true",
                     help="skip the short run with the other --encode-slots setting after the timed region (use under a tracer)")
     ap.add_argument("--encode-slots", type=int, default=1, choices=(1, 2),
-                    help="encode batches on the device at a time (library option encode_slots; 2 is worth -8 ... +8 %% end to end at 512x512 "
-                         "depending on the box and +6 %% at 1024x1024, but then every kernel's duration includes another batch's "
+                    help="encode batches on the device at a time (library option encode_slots; 2 is worth -8 ... +8 %% end to end depending on "
+                         "the box, but then every kernel's duration includes another batch's "
                          "DEFLATE pass next to it)")
     args = ap.parse_args()
     edge, n = WORKLOADS[args.config]
