@@ -98,9 +98,21 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	__syncthreads();
 	// digit histogram of this pass
 	if (FIRST) {
-		for (uint32_t p = tid; p < npos; p += 1024) {
-			const uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFFu;
-			atomicAdd(&offs[h & 255u], 1u);
+		// eight loads in flight per lane (the rolled loop waited for every load before its LDS add: 170 memory round trips in a
+		// row per lane); the low hash byte depends on in[p + 1] and in[p + 2] only
+		constexpr int U = 8;
+		const uint32_t lastp = npos ? npos - 1 : 0;
+		for (uint32_t p0 = tid; p0 < npos; p0 += 1024 * U) {
+			uint32_t w[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				const uint32_t p = min(p0 + (uint32_t)u * 1024u, lastp);
+				uint16_t x; __builtin_memcpy(&x, in + p + 1, 2);
+				w[u] = x;
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++)
+				if (p0 + (uint32_t)u * 1024u < npos) atomicAdd(&offs[(((w[u] & 255u) << 5) ^ (w[u] >> 8)) & 255u], 1u);
 		}
 	} else if (tid < NB) offs[tid] = a.sort_hist[(size_t)s * 128 + tid];
 	__syncthreads();
