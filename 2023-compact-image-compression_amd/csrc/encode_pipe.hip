@@ -488,8 +488,18 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 	const int n16 = NB / 16;                              // 16 blocks per chunk, 16 chunks per tile
 	const int cpl = (n16 + K2T - 1) / K2T;                // chunks per lane (contiguous ranges keep the order)
 	uint32_t cnt = 0;
-	for (int c = tid * cpl; c < min(n16, (tid + 1) * cpl); c++) {
-		const u32x4 v = *reinterpret_cast<const u32x4 *>(ssz + (size_t)c * 16);
+	// a lane's chunks, all requested before the first is used and kept for the second walk below (a rolled loop waits for
+	// every load where it is issued: four memory round trips in a row, twice).  Up to 512x512 a lane owns at most four chunks.
+	constexpr int CPL_REG = 4;
+	const bool in_regs = cpl <= CPL_REG;
+	const int c_lo = tid * cpl, c_hi = min(n16, (tid + 1) * cpl);
+	u32x4 vr[CPL_REG];
+	if (in_regs) {
+#pragma unroll
+		for (int k = 0; k < CPL_REG; k++) vr[k] = *reinterpret_cast<const u32x4 *>(ssz + (size_t)min(c_lo + k, n16 - 1) * 16);
+	}
+	auto chunk_of = [&](int c, int k) -> u32x4 { return in_regs ? vr[k] : *reinterpret_cast<const u32x4 *>(ssz + (size_t)c * 16); };
+	auto count_chunk = [&](int c, const u32x4 &v) {
 		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 		uint32_t sum = 0;
 #pragma unroll
@@ -498,13 +508,16 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 			sum = __builtin_amdgcn_udot4(w[q] & 0x7F7F7F7Fu, 0x01010101u, sum, false);
 		}
 		lds_add(&tsum[c >> 3], (int32_t)sum);
-	}
+	};
+	if (in_regs) {
+#pragma unroll
+		for (int k = 0; k < CPL_REG; k++) if (c_lo + k < c_hi) count_chunk(c_lo + k, vr[k]);
+	} else for (int c = c_lo; c < c_hi; c++) count_chunk(c, chunk_of(c, 0));
 	uint32_t ndiff;
 	uint32_t pos = wg_incl_scan256(cnt, misc, tid, ndiff) - cnt;
 	stamp<STAMP>(st, 1);
 	if (seg && ndiff) {
-		for (int c = tid * cpl; c < min(n16, (tid + 1) * cpl); c++) {
-			const u32x4 v = *reinterpret_cast<const u32x4 *>(ssz + (size_t)c * 16);
+		auto list_chunk = [&](int c, const u32x4 &v) {
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
@@ -517,10 +530,21 @@ __global__ void __launch_bounds__(K2T) pipe_resolve_kernel(PipeArgs a, uint64_t 
 					pos++;
 				}
 			}
-		}
+		};
+		if (in_regs) {
+#pragma unroll
+			for (int k = 0; k < CPL_REG; k++) if (c_lo + k < c_hi) list_chunk(c_lo + k, vr[k]);
+		} else for (int c = c_lo; c < c_hi; c++) list_chunk(c, chunk_of(c, 0));
 		__syncthreads();
-		// all masks with independent loads (one round trip)
-		for (uint32_t e = tid; e < min(ndiff, (uint32_t)K2_CAP); e += K2T) l_mask[e] = gmask[l_idx[e]];
+		// all masks with independent loads, eight in flight per lane
+		const uint32_t nm = min(ndiff, (uint32_t)K2_CAP);
+		for (uint32_t e0 = tid; e0 < nm; e0 += K2T * 8) {
+			uint64_t mv[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) mv[u] = gmask[l_idx[min(e0 + (uint32_t)u * K2T, nm - 1)]];
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (e0 + (uint32_t)u * K2T < nm) l_mask[e0 + (uint32_t)u * K2T] = mv[u];
+		}
 	}
 	__syncthreads();
 	stamp<STAMP>(st, 2);
