@@ -1467,19 +1467,28 @@ __global__ void __launch_bounds__(256) dfl_adler_kernel(DeflateArgs a)
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	unsigned long long A = 0, B = 0;
-	for (uint32_t i0 = threadIdx.x * 16; i0 < L; i0 += blockDim.x * 16) {
-		if (i0 + 16 <= L) {  // 16 bytes per step: A += sum d, B += (L - i0) * sum d - sum k * d_k
-			uint64_t w[2];
-			__builtin_memcpy(w, in + i0, 16);
+	// 16 bytes per step: A += sum d, B += (L - i0) * sum d - sum k * d_k.  Eight steps' loads are in flight together (the rolled
+	// loop waited for each one: one workgroup per slice, nothing else hides the latency)
+	const uint32_t nfull = L / 16;
+	constexpr int U = 8;
+	for (uint32_t g0 = threadIdx.x; g0 < nfull; g0 += blockDim.x * U) {
+		uint4 v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) v[u] = *reinterpret_cast<const uint4 *>(in + (size_t)min(g0 + (uint32_t)u * blockDim.x, nfull - 1) * 16);
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const uint32_t g = g0 + (uint32_t)u * blockDim.x;
+			if (g >= nfull) continue;
+			const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 			uint32_t sd = 0, sk = 0;
 #pragma unroll
-			for (int k = 0; k < 16; k++) { const uint32_t d = (uint32_t)(w[k >> 3] >> ((k & 7) * 8)) & 0xFFu; sd += d; sk += (uint32_t)k * d; }
+			for (int k = 0; k < 16; k++) { const uint32_t d = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu; sd += d; sk += (uint32_t)k * d; }
 			A += sd;
-			B += (unsigned long long)(L - i0) * sd - sk;
-		} else {
-			for (uint32_t i = i0; i < L; i++) { const unsigned long long d = in[i]; A += d; B += (unsigned long long)(L - i) * d; }
+			B += (unsigned long long)(L - g * 16) * sd - sk;
 		}
 	}
+	if (threadIdx.x == 0)
+		for (uint32_t i = nfull * 16; i < L; i++) { const unsigned long long d = in[i]; A += d; B += (unsigned long long)(L - i) * d; }
 	sa[threadIdx.x] = A; sb[threadIdx.x] = B;
 	__syncthreads();
 	for (int st = 128; st > 0; st >>= 1) {
