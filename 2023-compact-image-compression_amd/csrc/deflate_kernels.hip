@@ -603,18 +603,20 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 	const uint32_t nre = a.run_end_count[s];
 	for (uint32_t e = part * blockDim.x + threadIdx.x; e < ndeep; e += nparts * blockDim.x) {
 		const uint32_t i = *(deep - e);
+		// the four records a position can need depend on its sorted index only: requested together (clamped, not tested)
 		const uint64_t ri = recs[i];
+		const uint64_t r_head = recs[i >= 1 ? i - 1 : 0], r_1024 = recs[i >= 1024 ? i - 1024 : 0], r_4096 = recs[i >= 4096 ? i - 4096 : 0];
 		const uint32_t p = (uint32_t)ri;
 		const uint32_t h = (uint32_t)(ri >> 32);
 		const uint32_t lookahead = L - p;
 		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
-		const uint8_t b = in[p];
+		const uint8_t b = in[p], b_prev = in[p >= 1 ? p - 1 : 0];
 		const uint32_t r = mr[p].x >> 16;  // run length from p, capped at max_len (left by dfl_match_kernel)
-		const bool has_prev = p >= 2 && in[p - 1] == b;  // position 0 is NIL
+		const bool has_prev = p >= 2 && b_prev == b;  // position 0 is NIL
 		uint32_t best4 = has_prev ? r : 0u, q4 = p - 1, best1 = best4, q1 = p - 1;
 		bool scan = true;
 		if (!has_prev) {  // chain head rules of deflate_slow / longest_match
-			const uint64_t rh = i >= 1 ? recs[i - 1] : ~0ull;
+			const uint64_t rh = i >= 1 ? r_head : ~0ull;
 			const bool have_head = i >= 1 && (uint32_t)(rh >> 32) == h;
 			const uint32_t hq = have_head ? (uint32_t)rh : 0u;
 			if (!have_head || hq == 0 || hq == nil_candidate(p, lookahead) || p - hq > (uint32_t)MAX_DIST) scan = false;
@@ -630,8 +632,8 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 			const uint8_t c = ext_ok ? in[p + r] : 0;
 			const uint32_t qw = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1 : 1u;  // dist < MAX_DIST, q != NIL
 			uint32_t qmin4 = qw, qmin1 = qw;
-			if (i >= 4096) { const uint64_t r4 = recs[i - 4096]; if ((uint32_t)(r4 >> 32) == h) qmin4 = max(qmin4, (uint32_t)r4); }
-			if (i >= 1024) { const uint64_t r1 = recs[i - 1024]; if ((uint32_t)(r1 >> 32) == h) qmin1 = max(qmin1, (uint32_t)r1); }
+			if (i >= 4096 && (uint32_t)(r_4096 >> 32) == h) qmin4 = max(qmin4, (uint32_t)r_4096);
+			if (i >= 1024 && (uint32_t)(r_1024 >> 32) == h) qmin1 = max(qmin1, (uint32_t)r_1024);
 			uint32_t lo = 0, hi = nre;  // last run end <= p (none lies strictly inside p's own run)
 			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
