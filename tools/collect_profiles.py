@@ -40,7 +40,7 @@ def main():
     keep = ["bench.json", "bench_under_rocprof.json", "bench_kernel_stats.csv", "bench_two_slots.json",
             "bench_two_slots_under_rocprof.json", "bench_two_slots_kernel_stats.csv", "bench_no_overlap.json",
             "bench_config4.json", "bench_config5.json", "pmc_FETCH_SIZE_counter_collection.csv",
-            "pmc_WRITE_SIZE_counter_collection.csv", "pmc_sq_counter_collection.csv", "prof_encode.log", "prof_codec.log"]
+            "pmc_WRITE_SIZE_counter_collection.csv", "pmc_sq_counter_collection.csv", "prof_encode.log", "prof_codec.log", "codec_serial_kernel_stats.csv"]
     for name in keep:
         p = os.path.join(SRC, name)
         if os.path.exists(p):

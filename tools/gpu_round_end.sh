@@ -34,6 +34,9 @@ timeout -k 10 200 python tools/prof_encode.py --paths 1,2 --reps 30 > $O/prof_en
 # every stage alone (serial calls, nothing else on the device), and the INFLATE kernel's phase profile for both geometries
 timeout -k 10 200 python tools/prof_codec.py --reps 5 > $O/prof_codec.log 2>&1
 CCT_INF_PROF=1 timeout -k 10 200 python tools/prof_codec.py --reps 1 --what dec 2>&1 | grep "inflate prof" | head -1 >> $O/prof_codec.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2 -- python tools/prof_codec.py --reps 5 > $O/prof_codec_traced.log 2>&1
+find $O/prof2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/codec_serial_kernel_stats.csv
+rm -rf $O/prof2
 echo "pmc done"
 python -c "
 import json
