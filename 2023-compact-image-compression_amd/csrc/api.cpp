@@ -111,12 +111,12 @@ constexpr int N_ENC_SLOTS = 2;
 // them the archive upload of one batch runs under the INFLATE and decode kernels of the other (what bounds a decode-only
 // caller: BASELINE configs[4]).
 struct DecSlot {
-	std::mutex mu;
 	hipStream_t stream = nullptr;  // slot 0: Context::stream_dec
 	DevBuf d_role, d_slot, d_jord, d_jval, d_payload, d_sizes, d_status, d_images, d_pcache;
 	DevBuf d_arch, d_archoffs, d_zstatus;
 	DevBuf dh_stage;  // pinned host staging of inflated payloads (host INFLATE path)
 	hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr, ev_k_dec0 = nullptr, ev_k_dec1 = nullptr;
+	hipEvent_t ev_ws = nullptr;  // recorded after a launch on ANOTHER stream that uses this slot's workspaces (cct_decode_payload_dev)
 	DevBuf *all_bufs[16];
 	int n_bufs = 0;
 	DecSlot()
@@ -191,6 +191,7 @@ void reset_ctx()
 // decode driven from two threads do not overwrite each other's numbers
 thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
 std::mutex g_mu1;     // encode slot 1
+std::mutex g_mu_dec[N_DEC_SLOTS];  // the decode slots; like g_mu / g_mu1 they outlive reset_ctx(), which replaces the slot objects
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
 
 int default_device()
@@ -257,6 +258,7 @@ int ensure_ctx(int device)
 		HIP_TRY(hipEventCreate(&D.ev_d1));
 		HIP_TRY(hipEventCreate(&D.ev_k_dec0));
 		HIP_TRY(hipEventCreate(&D.ev_k_dec1));
+		HIP_TRY(hipEventCreateWithFlags(&D.ev_ws, hipEventDisableTiming));
 	}
 	HIP_TRY(deflate_init_tables());  // __constant__ tables of the DEFLATE kernels, shared by both encode slots
 	g_ctx.device = dev;
@@ -490,21 +492,31 @@ void build_tile_tables(const std::vector<int32_t> &O, int width, ShapeTables &t)
 
 int get_tables(int width, int height, const ShapeTables **out)
 {
-	std::lock_guard<std::mutex> lkl(g_mu_lut);
-	auto key = std::make_pair(width, height);
-	auto it = g_ctx.luts.find(key);
-	if (it != g_ctx.luts.end()) { *out = &it->second; return CCT_OK; }
+	const auto key = std::make_pair(width, height);
+	{
+		std::lock_guard<std::mutex> lkl(g_mu_lut);
+		auto it = g_ctx.luts.find(key);
+		if (it != g_ctx.luts.end()) { *out = &it->second; return CCT_OK; }
+	}
+	// a new shape: the traversal is generated on the host with no lock held; the device allocations and the synchronous
+	// copies of the tables run with nothing else of the library in flight (host.h), and g_mu_lut is taken INSIDE the
+	// exclusive section (the other order would invert against a thread that holds g_mu_lut and asks for the section)
 	const size_t N = (size_t)width * height;
 	std::vector<int32_t> host(N ? N : 1);
 	if (!gilbert_table(width, height, host.data())) return fail(CCT_E_SHAPE, "traversal generation failed for %dx%d", width, height);
 	host.resize(N);
-	ShapeTables t;
-	HIP_TRY(hipMalloc(&t.d_lut, (N ? N : 1) * sizeof(int32_t)));
-	HIP_TRY(hipMemcpy(t.d_lut, host.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
-	build_tile_tables(host, width, t);
-	auto ins = g_ctx.luts.emplace(key, t);
-	*out = &ins.first->second;
-	return CCT_OK;
+	return exclusive_section([&]() -> int {
+		std::lock_guard<std::mutex> lkl(g_mu_lut);
+		auto it = g_ctx.luts.find(key);
+		if (it != g_ctx.luts.end()) { *out = &it->second; return CCT_OK; }  // another thread built it meanwhile
+		ShapeTables t;
+		HIP_TRY(hipMalloc(&t.d_lut, (N ? N : 1) * sizeof(int32_t)));
+		HIP_TRY(hipMemcpy(t.d_lut, host.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+		build_tile_tables(host, width, t);
+		auto ins = g_ctx.luts.emplace(key, t);
+		*out = &ins.first->second;
+		return CCT_OK;
+	});
 }
 
 int get_lut(int width, int height, const int32_t **out)
@@ -811,6 +823,12 @@ int decode_payload_locked(DecSlot &D, const uint8_t *d_payload, size_t stride, c
 	if ((rc = D.d_pcache.ensure((size_t)n * a.pcache_steps * g_ctx.wg_threads * sizeof(uint2)))) return rc;
 	a.ws_pcache = (uint2 *)D.d_pcache.p;
 	HIP_TRY(launch_decode(a, n, bs, g_ctx.wg_threads, st));
+	if (st != D.stream) {
+		// the kernel is still queued on the caller's stream when the slot is released: whatever takes the slot next runs on
+		// D.stream and must not touch d_role / d_slot / d_jord / d_pcache before this launch is through
+		HIP_TRY(hipEventRecord(D.ev_ws, st));
+		HIP_TRY(hipStreamWaitEvent(D.stream, D.ev_ws, 0));
+	}
 	return CCT_OK;
 }
 
@@ -834,8 +852,8 @@ int cct_shutdown(void)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	std::lock_guard<std::mutex> lk1(g_mu1);
-	std::lock_guard<std::mutex> lkd0(g_dec[0].mu);
-	std::lock_guard<std::mutex> lkd1(g_dec[1].mu);
+	std::lock_guard<std::mutex> lkd0(g_mu_dec[0]);
+	std::lock_guard<std::mutex> lkd1(g_mu_dec[1]);
 	if (!g_ctx.ready || g_ctx.pid != getpid()) { reset_ctx(); return CCT_OK; }
 	(void)hipSetDevice(g_ctx.device);
 	(void)hipStreamSynchronize(g_ctx.stream);
@@ -863,7 +881,7 @@ int cct_shutdown(void)
 		DecSlot &D = g_dec[k];
 		if (D.stream) (void)hipStreamSynchronize(D.stream);
 		for (int i = 0; i < D.n_bufs; i++) D.all_bufs[i]->release();
-		hipEvent_t evs[] = {D.ev_d0, D.ev_d1, D.ev_k_dec0, D.ev_k_dec1};
+		hipEvent_t evs[] = {D.ev_d0, D.ev_d1, D.ev_k_dec0, D.ev_k_dec1, D.ev_ws};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 		if (k > 0 && D.stream) (void)hipStreamDestroy(D.stream);
 	}
@@ -891,34 +909,36 @@ int cct_dev_alloc(void **d_ptr, size_t bytes)
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = ensure_ctx();
 	if (rc) return rc;
-	HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
-	return CCT_OK;
+	return exclusive_section([&]() -> int { HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1)); return CCT_OK; });
 }
 int cct_dev_free(void *d_ptr)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = ensure_ctx();
 	if (rc) return rc;
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-	HIP_TRY(hipFree(d_ptr));
-	return CCT_OK;
+	return exclusive_section([&]() -> int {  // hipFree waits for the whole device: not next to a capture (host.h)
+		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		HIP_TRY(hipFree(d_ptr));
+		return CCT_OK;
+	});
 }
 int cct_host_alloc(void **h_ptr, size_t bytes)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = ensure_ctx();
 	if (rc) return rc;
-	HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
-	return CCT_OK;
+	return exclusive_section([&]() -> int { HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return CCT_OK; });
 }
 int cct_host_free(void *h_ptr)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	int rc = ensure_ctx();
 	if (rc) return rc;
-	HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-	HIP_TRY(hipHostFree(h_ptr));
-	return CCT_OK;
+	return exclusive_section([&]() -> int {
+		HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+		HIP_TRY(hipHostFree(h_ptr));
+		return CCT_OK;
+	});
 }
 // is [p, p + bytes) page-locked host memory (cct_host_alloc / hipHostMalloc / hipHostRegister)?
 static bool is_pinned_host(const void *p, size_t bytes)
@@ -1412,7 +1432,7 @@ static DecSlot &acquire_decode_slot(std::unique_lock<std::mutex> &lk)
 	const int nslots = std::max(1, std::min(g_ctx.dec_slots, N_DEC_SLOTS));
 	for (;;) {
 		for (int k = 0; k < nslots; k++) {
-			std::unique_lock<std::mutex> t(g_dec[k].mu, std::try_to_lock);
+			std::unique_lock<std::mutex> t(g_mu_dec[k], std::try_to_lock);
 			if (t.owns_lock()) { lk = std::move(t); return g_dec[k]; }
 		}
 		std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -1422,16 +1442,19 @@ static DecSlot &acquire_decode_slot(std::unique_lock<std::mutex> &lk)
 int cct_zlib_decompress_batch(const uint8_t *h_in, const uint64_t *h_offsets, int n, uint8_t *h_out, size_t out_stride,
                               uint32_t *h_out_sizes, uint32_t *h_status)
 {
-	std::unique_lock<std::mutex> lkd;
-	DecSlot &D = acquire_decode_slot(lkd);
-	ApiCall in_call;
 	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
 	if (out_stride == 0 || (out_stride & 15)) return fail(CCT_E_ARG, "out_stride must be a positive multiple of 16");
+	// first use in this process: bind the device BEFORE the slot and the shared lock are taken.  A thread must never wait
+	// for g_mu while it counts as a call in flight: a first encode holds g_mu through HIP initialisation and then asks
+	// for an exclusive section, which waits for every call in flight to leave
 	if (!(g_ctx.ready && g_ctx.pid == getpid())) {
 		std::lock_guard<std::mutex> lk(g_mu);
 		int rc0 = ensure_ctx();
 		if (rc0) return rc0;
 	}
+	std::unique_lock<std::mutex> lkd;
+	DecSlot &D = acquire_decode_slot(lkd);
+	ApiCall in_call;
 	if (n == 0) return CCT_OK;
 	int rc;
 	HIP_TRY(hipSetDevice(g_ctx.device));
@@ -1493,7 +1516,7 @@ int cct_read_header(const uint8_t *h_file, size_t len, const char magic[4], cct_
 int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, const uint32_t *d_payload_sizes, int n,
                            int width, int height, int block_size, int fractal, uint16_t *d_images, uint32_t *d_status)
 {
-	std::lock_guard<std::mutex> lkd(g_dec[0].mu);  // the workspaces of decode slot 0, on the main stream
+	std::lock_guard<std::mutex> lkd(g_mu_dec[0]);  // the workspaces of decode slot 0
 	std::lock_guard<std::mutex> lk(g_mu);
 	ApiCall in_call;
 	int rc = check_shape(n, width, height, block_size);
@@ -1506,11 +1529,16 @@ int cct_decode_payload_dev(const uint8_t *d_payload, size_t payload_stride, cons
 int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, int block_size, const char magic[4],
                      uint16_t *images, int images_on_device, size_t images_cap_px, uint32_t *h_status)
 {
+	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
+	if (n == 0) return CCT_OK;
+	if (!(g_ctx.ready && g_ctx.pid == getpid())) {  // first use in this process: bind the device before slot and shared lock (see above)
+		std::lock_guard<std::mutex> lk(g_mu);
+		int rc0 = ensure_ctx();
+		if (rc0) return rc0;
+	}
 	std::unique_lock<std::mutex> lkd;
 	DecSlot &D = acquire_decode_slot(lkd);
 	ApiCall in_call;
-	if (n < 0) return fail(CCT_E_ARG, "negative batch size");
-	if (n == 0) return CCT_OK;
 	cct_header h0;
 	int rc = cct_read_header(h_files + h_offsets[0], (size_t)(h_offsets[1] - h_offsets[0]), magic, &h0);
 	if (rc) return rc;
@@ -1526,10 +1554,6 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 	if (images_cap_px < (size_t)n * N) return fail(CCT_E_CAP, "output holds %zu pixels, need %zu", images_cap_px, (size_t)n * N);
 	const size_t stride = cct_payload_stride(h0.width, h0.height, block_size);
 	int zthreads = 1;
-	if (!(g_ctx.ready && g_ctx.pid == getpid())) {  // first use in this process: bind the device
-		std::lock_guard<std::mutex> lk(g_mu);
-		if ((rc = ensure_ctx())) return rc;
-	}
 	{  // the slot's own buffers; no device lock, encodes and the other decode slot may be in flight
 		HIP_TRY(hipSetDevice(g_ctx.device));
 		if ((rc = D.dh_stage.ensure((size_t)n * stride))) return rc;

@@ -91,11 +91,14 @@ int cct_comm_init(const void *id128, int rank, int world)
 	cct_unique_id_t id;
 	memcpy(&id, id128, CCT_COMM_ID_BYTES);
 	std::lock_guard<std::mutex> lkc(g_rccl.mu);
-	if (!g_rccl.stream) HIP_TRY(hipStreamCreateWithFlags(&g_rccl.stream, hipStreamNonBlocking));
-	const int r = g_rccl.CommInitRank(&g_rccl.comm, world, id, rank);
-	if (r) { g_rccl.comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
-	g_rccl.rank = rank; g_rccl.world = world;
-	return CCT_OK;
+	// stream creation and the communicator's own allocations: with nothing else of the library in flight (host.h)
+	return exclusive_section([&]() -> int {
+		if (!g_rccl.stream) HIP_TRY(hipStreamCreateWithFlags(&g_rccl.stream, hipStreamNonBlocking));
+		const int r = g_rccl.CommInitRank(&g_rccl.comm, world, id, rank);
+		if (r) { g_rccl.comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
+		g_rccl.rank = rank; g_rccl.world = world;
+		return CCT_OK;
+	});
 }
 
 int cct_comm_info(int *rank, int *world)
@@ -115,6 +118,7 @@ int cct_allgather_u32(const uint32_t *h_local, int n_local, int max_local, uint3
 		return CCT_OK;
 	}
 	if (forked_after_init()) return fail(CCT_E_DEVICE, "this process was forked after the communicator was created");
+	ApiCall in_call;  // a call in flight like the others: captures and allocations of other threads wait for it (host.h)
 	HIP_TRY(hipSetDevice(bound_device()));
 	int rc;
 	const size_t bytes = (size_t)std::max(max_local, 1) * 4;
@@ -134,9 +138,11 @@ int cct_comm_destroy(void)
 	std::lock_guard<std::mutex> lk(g_rccl.mu);
 	if (g_rccl.comm) { (void)g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
 	g_rccl.rank = -1; g_rccl.world = 0;
-	g_rccl.d_send.release(); g_rccl.d_recv.release();
-	if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
-	return CCT_OK;
+	return exclusive_section([&]() -> int {
+		g_rccl.d_send.release(); g_rccl.d_recv.release();
+		if (g_rccl.stream) { (void)hipStreamDestroy(g_rccl.stream); g_rccl.stream = nullptr; }
+		return CCT_OK;
+	});
 }
 
 }  // extern "C"

@@ -30,7 +30,7 @@ static int packbits_batch(bool encode, const uint8_t *h_in, const uint64_t *h_of
 	}
 	if (encode && out_stride < cct_packbits_bound(longest)) return fail(CCT_E_CAP, "out_stride %zu below cct_packbits_bound(%zu)", out_stride, longest);
 	DevBuf d_in, d_offs, d_ws, d_out, d_sizes, d_status;
-	auto release = [&] { d_in.release(); d_offs.release(); d_ws.release(); d_out.release(); d_sizes.release(); d_status.release(); };
+	auto release = [&] { exclusive_section([&]() -> int { d_in.release(); d_offs.release(); d_ws.release(); d_out.release(); d_sizes.release(); d_status.release(); return 0; }); };
 	if ((rc = d_in.ensure(total + 16)) || (rc = d_offs.ensure((size_t)(n + 1) * 8)) || (rc = d_ws.ensure((total + 1) * 4)) ||
 	    (rc = d_out.ensure((size_t)n * out_stride + 16)) || (rc = d_sizes.ensure((size_t)n * 4)) || (rc = d_status.ensure((size_t)n * 4))) { release(); return rc; }
 	hipError_t e = hipSuccess;

@@ -52,8 +52,6 @@ struct ApiCall {
 template <class F>
 auto exclusive_section(F f) -> decltype(f())
 {
-	static const bool off = getenv("CCT_NO_QUIESCE") != nullptr;  // debugging only: the behaviour before this lock existed
-	if (off) return f();
 	const bool shared = tl_api_depth > 0;
 	if (shared) g_quiesce.unlock_shared();
 	g_quiesce.lock();
@@ -77,11 +75,14 @@ struct DevBuf {  // grow-only device (or pinned host) buffer
 			return CCT_OK;
 		});
 	}
+	// hipFree / hipHostFree wait for the whole device: callers run them inside an exclusive section (ensure() does) or with
+	// every stream of the library drained (cct_shutdown)
 	void release()
 	{
 		if (p) { if (pinned_host) (void)hipHostFree(p); else (void)hipFree(p); }
 		p = nullptr; cap = 0;
 	}
+	void release_exclusive() { if (p) exclusive_section([&]() -> int { release(); return 0; }); }
 };
 
 extern std::mutex g_mu;          // device context, main stream (and with it encode slot 0), every plumbing call

@@ -112,6 +112,30 @@ def test_options_round_trip_without_a_device():
     assert L.cct_get_option(b"no_such_option", C.byref(v)) != 0
 
 
+def test_shutdown_twice_and_from_threads():
+    """cct_shutdown replaces the slot objects; the slot mutexes it holds meanwhile live outside them (round 2 destroyed
+    them while locked).  Twice in a row, and racing threads that poll options, must leave a usable library."""
+    import threading
+    import ctypes as C
+    from cct_hip import _ffi
+    L = _ffi.lib()
+    assert L.cct_shutdown() == 0 and L.cct_shutdown() == 0
+    stop = threading.Event()
+    def poll():
+        v = C.c_int(0)
+        while not stop.is_set():
+            assert L.cct_get_option(b"decode_slots", C.byref(v)) == 0
+    ts = [threading.Thread(target=poll) for _ in range(3)]
+    for t in ts:
+        t.start()
+    for _ in range(50):
+        assert L.cct_shutdown() == 0
+    stop.set()
+    for t in ts:
+        t.join()
+    assert L.cct_version() == 1
+
+
 def test_bench_traffic_figure_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
     """bench.py prints the PMC traffic of the transform+pack stage only while the SHA-1 stored with it is the SHA-1 of
     encode_pipe.hip; and the summary committed under profiles/ belongs to the source committed next to it."""
