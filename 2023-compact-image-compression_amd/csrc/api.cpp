@@ -56,6 +56,7 @@ struct ShapeTables {  // everything that depends on (width, height) only; lives 
 	uint32_t *d_btab = nullptr;       // n_orient * 256
 	uint32_t *d_otab = nullptr;       // 4 * 16
 	uint32_t *d_ttab = nullptr;       // 16 * 4
+	uint32_t *d_htab = nullptr;       // n_orient * 32 * 2 (encode_stream.hip: the look-ahead quadrant of a tile)
 	PipeTiles tiles;                  // host copy: travels in the kernel arguments
 };
 
@@ -84,6 +85,7 @@ struct EncSlot {
 	// encode workspaces
 	DevBuf e_role, e_lidx, e_lmask, e_lcur, e_images, e_payload, e_sizes, e_status, e_stats;
 	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
+	DevBuf e_hand;                               // streaming kernel: hand-off words and tickets
 	DevBuf h_stage;  // pinned host staging (payloads)
 	// device DEFLATE workspaces
 	DevBuf z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
@@ -96,7 +98,7 @@ struct EncSlot {
 	EncSlot()
 	{
 		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
-		               &e_spill, &e_tflag, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
+		               &e_spill, &e_tflag, &e_hand, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
 		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
 		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1]};
 		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
@@ -140,11 +142,12 @@ struct Context {
 	int enc_slots = N_ENC_SLOTS;  // option "encode_slots": 1 = one encode batch on the device at a time
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
-	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths, 3 staged pipeline (encode_pipe.hip) wherever it
-	                    // applies, 2 one-workgroup-per-slice tile kernel, 0 generic LUT-gather kernel
+	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths (the streaming kernel wherever it applies), 4 the
+	                    // streaming kernel (encode_stream.hip), 3 the four-kernel pipeline (encode_pipe.hip), 2 the
+	                    // one-workgroup-per-slice tile kernel, 0 the generic LUT-gather kernel
 	int pipe_tpw = 0, pipe_timing = 0;  // tuning options "pipe_tpw", "pipe_timing" (then "pipe_us_k1/k2/k3" hold the last kernel times)
 	float pipe_us[4] = {0, 0, 0, 0};
-	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel)
+	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel, 3 streaming kernel)
 	int dbg_skip = 0;   // option "debug_skip": phase-ablation mask for tuning runs (outputs invalid when set)
 	int device_deflate = 1;  // option "device_deflate": 0 = DEFLATE stage on the host thread team (libz)
 	int device_inflate = 1;  // option "device_inflate": 1 = INFLATE on the device (inflate_kernels.hip, speculative lane-parallel
@@ -426,11 +429,32 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 		ttab[f * 4 + 0] = seq[0] | seq[1] << 8 | seq[2] << 16 | (uint32_t)seq[3] << 24;
 		ttab[f * 4 + 1] = seq[4] | seq[5] << 8 | seq[6] << 16 | (uint32_t)seq[7] << 24;
 		ttab[f * 4 + 2] = (uint32_t)n;
+		uint32_t keep = 0x7F7F7F7Fu;  // bits of the deltas' low bytes that reach the stream: 7 of a short token, 8 of a full token's second byte
+		for (int px = 0; px < 4; px++) if (f >> px & 1) keep |= 0x80u << (8 * px);
+		ttab[f * 4 + 3] = keep;
+	}
+	// the first 64 traversal blocks of a tile (the look-ahead of the previous tile's mesh search) as 32 block pairs
+	std::vector<uint32_t> htab((size_t)no * 32 * 2, 0);
+	for (int to = 0; to < no; to++) {
+		int cnt = 0;
+		for (int lane = 0; lane < 128; lane++) {
+			const uint32_t *e = ptab.data() + ((size_t)to * 128 + lane) * 4;
+			const int ka = (int)(e[0] & 0xFF), kb = (int)((e[0] >> 16) & 0xFF);
+			if ((ka < 64) != (kb < 64)) return;
+			if (ka >= 64) continue;
+			if (cnt == 32) return;
+			htab[((size_t)to * 32 + cnt) * 2] = e[0];
+			htab[((size_t)to * 32 + cnt) * 2 + 1] = (uint32_t)((lane >> 3) * 4 * width + (lane & 7) * 8);
+			cnt++;
+		}
+		if (cnt != 32) return;
 	}
 	if (hipMalloc(&t.d_ptab, ptab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_btab, btab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_ptab2, ptab2.size() * 4) != hipSuccess) return;
 	if (hipMemcpy(t.d_ptab2, ptab2.data(), ptab2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
+	if (hipMalloc(&t.d_htab, htab.size() * 4) != hipSuccess) return;
+	if (hipMemcpy(t.d_htab, htab.data(), htab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
 	if (hipMalloc(&t.d_otab, otab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_ttab, ttab.size() * 4) != hipSuccess) return;
 	if (hipMemcpy(t.d_ptab, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return;
@@ -628,11 +652,67 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 	a.ws_lidx = (uint32_t *)E.e_lidx.p; a.ws_lmask = (uint64_t *)E.e_lmask.p; a.ws_lcur = (uint8_t *)E.e_lcur.p;
 	const ShapeTables *tb = nullptr;
 	if ((flags & CCT_FLAG_FRACTAL) && bs == 16 && g_ctx.use_tiles) { if ((rc = get_tables(width, height, &tb))) return rc; }
-	// the staged pipeline is the default up to 512x512 (measured: 212 / 225 us per 256 phantom / real slices against 215 / 236 us
-	// of the one-workgroup-per-slice kernel); at 1024x1024 the older kernel is faster (1.68 against 1.95 ms per 512 slices)
-	// and keeps the default; option "tile_path" = 3 forces the pipeline wherever it applies
-	const bool pipe_wanted = g_ctx.use_tiles == 3 || (g_ctx.use_tiles == 1 && NB <= PIPE_DEFAULT_MAX_NB);
-	if (tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && pipe_wanted && !g_ctx.dbg_skip) {
+	// a tile-path launch sequence (memset nodes + kernels), replayed as a graph from the second call with the same arguments
+	// on: no dispatch gaps between its nodes, fewer host calls
+	auto launch_or_replay = [&](const void *args, size_t args_bytes, int tag, const std::function<hipError_t()> &launch) -> int {
+		if (!g_ctx.use_graph) { HIP_TRY(launch()); return CCT_OK; }
+		std::vector<uint8_t> key(args_bytes + 2 * sizeof(int));
+		memcpy(key.data(), args, args_bytes);
+		memcpy(key.data() + args_bytes, &n, sizeof(int));
+		memcpy(key.data() + args_bytes + sizeof(int), &tag, sizeof(int));
+		EncSlot::PipeGraph *pg = nullptr;
+		for (auto &gr : E.p_graphs) if (gr.key == key) pg = &gr;
+		if (!pg) {
+			if (E.p_graphs.size() >= 6) {  // forget the least recently used argument set
+				size_t old = 0;
+				for (size_t i = 1; i < E.p_graphs.size(); i++) if (E.p_graphs[i].last_use < E.p_graphs[old].last_use) old = i;
+				exclusive_section([&]() -> int {
+					if (E.p_graphs[old].exec) (void)hipGraphExecDestroy(E.p_graphs[old].exec);
+					if (E.p_graphs[old].graph) (void)hipGraphDestroy(E.p_graphs[old].graph);
+					return 0;
+				});
+				E.p_graphs.erase(E.p_graphs.begin() + (long)old);
+			}
+			E.p_graphs.emplace_back();
+			E.p_graphs.back().key = key;
+			E.p_graphs.back().last_use = ++E.p_clock;
+			HIP_TRY(launch());  // first sight: plain launches (also sets the kernel attributes)
+			return CCT_OK;
+		}
+		pg->last_use = ++E.p_clock;
+		if (!pg->exec) {
+			const int crc = exclusive_section([&]() -> int {  // nothing else of the library runs during a capture (host.h)
+				HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+				hipError_t le = launch();
+				hipError_t ce = hipStreamEndCapture(st, &pg->graph);
+				if (le != hipSuccess) return fail(CCT_E_DEVICE, "tile-path capture: %s", hipGetErrorString(le));
+				HIP_TRY(ce);
+				HIP_TRY(hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0));
+				return CCT_OK;
+			});
+			if (crc) return crc;
+		}
+		HIP_TRY(hipGraphLaunch(pg->exec, st));
+		return CCT_OK;
+	};
+	// Choice among the tile paths (option "tile_path"): 1 = default: the streaming kernel (encode_stream.hip) wherever it
+	// applies; 4 forces it, 3 the four-kernel pipeline of round 2, 2 the one-workgroup-per-slice tile kernel of round 1,
+	// 0 the generic table-gather kernel.
+	const bool pipe_ok = tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && !g_ctx.dbg_skip;
+	const int gps = tb ? (tb->n_tiles + STREAM_TPG - 1) / STREAM_TPG : 0;
+	if (pipe_ok && gps <= STREAM_MAX_GPS && (g_ctx.use_tiles == 1 || g_ctx.use_tiles == 4)) {
+		if ((rc = E.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
+		if ((rc = E.e_hand.ensure(stream_ws_bytes(n, gps)))) return rc;
+		StreamArgs sa{};
+		sa.e = a;
+		sa.tiles = tb->tiles; sa.ptab = tb->d_ptab; sa.htab = tb->d_htab; sa.otab = tb->d_otab; sa.ttab = tb->d_ttab;
+		sa.n_tiles = tb->n_tiles; sa.row_pitch = width; sa.gps = gps;
+		sa.hand = (uint64_t *)E.e_hand.p; sa.ticket = (uint32_t *)(sa.hand + (size_t)n * gps * 4);
+		sa.spill_mask = (uint64_t *)E.e_lmask.p; sa.spill_idx = (uint8_t *)E.e_lcur.p; sa.pairrec = (uint8_t *)E.e_pairrec.p;
+		g_ctx.last_path = 3;
+		return launch_or_replay(&sa, sizeof sa, 4, [&]() { return launch_encode_stream(sa, n, st); });
+	}
+	if (pipe_ok && g_ctx.use_tiles == 3) {
 		const int NT = tb->n_tiles;
 		if ((rc = E.e_role.ensure(per))) return rc;
 		if ((rc = E.e_toff.ensure((size_t)n * (2 * NT + 1) * 4))) return rc;
@@ -651,47 +731,7 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 		PipeTune tune{g_ctx.pipe_tpw, g_ctx.pipe_timing ? g_ctx.pipe_us : nullptr};
 		g_ctx.last_path = 1;
 		static const bool stamps = getenv("CCT_PIPE_STAMPS") != nullptr;
-		if (g_ctx.use_graph && !g_ctx.pipe_timing && !stamps) {
-			// replayed as a graph from the second call with the same arguments on: no dispatch gaps between the five nodes
-			std::vector<uint8_t> key(sizeof(PipeArgs) + 2 * sizeof(int));
-			memcpy(key.data(), &pa, sizeof(PipeArgs));
-			memcpy(key.data() + sizeof(PipeArgs), &n, sizeof(int));
-			memcpy(key.data() + sizeof(PipeArgs) + sizeof(int), &tune.tpw, sizeof(int));
-			EncSlot::PipeGraph *pg = nullptr;
-			for (auto &g : E.p_graphs) if (g.key == key) pg = &g;
-			if (!pg) {
-				if (E.p_graphs.size() >= 6) {  // forget the least recently used argument set
-					size_t old = 0;
-					for (size_t i = 1; i < E.p_graphs.size(); i++) if (E.p_graphs[i].last_use < E.p_graphs[old].last_use) old = i;
-					exclusive_section([&]() -> int {
-						if (E.p_graphs[old].exec) (void)hipGraphExecDestroy(E.p_graphs[old].exec);
-						if (E.p_graphs[old].graph) (void)hipGraphDestroy(E.p_graphs[old].graph);
-						return 0;
-					});
-					E.p_graphs.erase(E.p_graphs.begin() + (long)old);
-				}
-				E.p_graphs.emplace_back();
-				E.p_graphs.back().key = key;
-				E.p_graphs.back().last_use = ++E.p_clock;
-				HIP_TRY(launch_encode_pipe(pa, n, st, &tune));  // first sight: plain launches (also sets the kernel attributes)
-				return CCT_OK;
-			}
-			pg->last_use = ++E.p_clock;
-			if (!pg->exec) {
-				const int crc = exclusive_section([&]() -> int {  // nothing else of the library runs during a capture (host.h)
-					HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-					hipError_t le = launch_encode_pipe(pa, n, st, &tune);
-					hipError_t ce = hipStreamEndCapture(st, &pg->graph);
-					if (le != hipSuccess) return fail(CCT_E_DEVICE, "pipeline capture: %s", hipGetErrorString(le));
-					HIP_TRY(ce);
-					HIP_TRY(hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0));
-					return CCT_OK;
-				});
-				if (crc) return crc;
-			}
-			HIP_TRY(hipGraphLaunch(pg->exec, st));
-			return CCT_OK;
-		}
+		if (!g_ctx.pipe_timing && !stamps) return launch_or_replay(&pa, sizeof pa, tune.tpw, [&]() { return launch_encode_pipe(pa, n, st, &tune); });
 		HIP_TRY(launch_encode_pipe(pa, n, st, &tune));
 		return CCT_OK;
 	}
@@ -874,7 +914,7 @@ int cct_shutdown(void)
 	comm_release();
 	for (auto &kv : g_ctx.luts) {
 		ShapeTables &t = kv.second;
-		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab};
+		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab, t.d_htab};
 		for (void *p : ptrs) if (p) (void)hipFree(p);
 	}
 	for (int k = 0; k < N_DEC_SLOTS; k++) {
@@ -1686,7 +1726,7 @@ int cct_set_option(const char *key, int value)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
-	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = (value >= 0 && value <= 3) ? value : 1; return CCT_OK; }
+	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = (value >= 0 && value <= 4) ? value : 1; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "pipe_tpw")) { g_ctx.pipe_tpw = value; return CCT_OK; }
 	if (!strcmp(key, "pipe_timing")) { g_ctx.pipe_timing = value; return CCT_OK; }

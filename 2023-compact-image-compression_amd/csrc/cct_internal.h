@@ -91,6 +91,26 @@ struct PipeTune {   // tuning runs only
 };
 hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const PipeTune *tune = nullptr);
 
+// single streaming pass (encode_stream.hip): same applicability as the pipeline; one kernel, every pixel read once
+constexpr int STREAM_TPG = 4;       // tiles per group = waves per workgroup
+constexpr int STREAM_MAX_GPS = 64;  // groups per slice: a group collects its predecessors' totals with one lane each
+struct StreamArgs {
+	EncArgs e;
+	PipeTiles tiles;
+	const uint32_t *ptab;        // as PipeArgs::ptab
+	const uint32_t *htab;        // n_orient * 32 entries of 2 dwords: the 32 block pairs that make up a tile's first 64 traversal blocks:
+	                             //   [0] as ptab[0], [1] raster offset inside the tile of the pair's 8x4-pixel region
+	const uint32_t *otab, *ttab; // as PipeArgs (ttab entry: selectors, token bytes, kept bits of the low bytes)
+	int n_tiles, row_pitch, gps; // gps: groups per slice
+	uint64_t *hand;              // n * gps * 4 hand-off words, then
+	uint32_t *ticket;            // n group tickets (one allocation: zeroed by one memset before every launch)
+	uint64_t *spill_mask;        // n * NB: candidate masks beyond the LDS list of a tile
+	uint8_t *spill_idx;          // n * NB: their blocks
+	uint8_t *pairrec;            // n * (NB / 2) * PIPE_PAIR_REC: meshed pairs beyond one per lane
+};
+inline size_t stream_ws_bytes(int n, int gps) { return ((size_t)n * gps * 32 + (size_t)n * 4 + 15) & ~(size_t)15; }
+hipError_t launch_encode_stream(const StreamArgs &sa, int n, hipStream_t s);
+
 size_t enc_lds_bytes(int NB, bool *role_in_lds);
 hipError_t launch_encode(const EncArgs &a, int n, int block_size, int threads, hipStream_t s);
 

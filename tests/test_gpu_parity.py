@@ -435,9 +435,10 @@ def _last_path(L):
 
 @pytest.mark.parametrize("n_px", [128, 256, 512, 1024])
 def test_tile_path_equals_generic_path(hip, n_px):
-    """Three implementations of stage (i) must agree byte for byte (payload, sizes, statistics, block roles) -- and
-    with the oracle: the staged pipeline (encode_pipe.hip, the default), the one-workgroup-per-slice tile kernel
-    and the generic LUT-gather kernel.  The test also checks that each path really ran (no silent fallback)."""
+    """Four implementations of stage (i) must agree byte for byte (payload, sizes, statistics, block roles) -- and
+    with the oracle: the streaming kernel (encode_stream.hip, the default), the four-kernel pipeline (encode_pipe.hip),
+    the one-workgroup-per-slice tile kernel and the generic LUT-gather kernel.  The test also checks that each path
+    really ran (no silent fallback)."""
     from oracle import oracle
     from cct_hip import DeviceBuffer, codec_params, encode_payload_dev, _ffi
     from cct_hip.batch import payload_stride
@@ -455,7 +456,7 @@ def test_tile_path_equals_generic_path(hip, n_px):
     stride = payload_stride(w, h, 16)
     d_img = DeviceBuffer.from_numpy(imgs)
     res = []
-    for tile, ran in ((3, 1), (2, 2), (0, 0)):  # option value, implementation that must have run
+    for tile, ran in ((4, 3), (3, 1), (2, 2), (0, 0)):  # option value, implementation that must have run
         _ffi.check(L.cct_set_option(b"tile_path", tile))
         d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
         d_stats, d_roles = DeviceBuffer(16 * n), DeviceBuffer(n * nb)
@@ -477,21 +478,22 @@ def test_tile_path_equals_generic_path(hip, n_px):
 
 
 def test_default_path_by_shape(hip):
-    """The default choice among the tile paths: staged pipeline up to 512x512, one-workgroup-per-slice kernel at 1024x1024."""
+    """The default choice among the tile paths: the streaming kernel wherever the traversal is made of 64x64 tiles of 4x4 blocks."""
     from cct_hip import _ffi
     L = _ffi.lib()
     cfg = hip.default_config()
     hip.encode_batch(gi.ct_phantom(3, 512)[None], cfg)
-    assert _last_path(L) == 1
+    assert _last_path(L) == 3
     hip.encode_batch(gi.ct_phantom(3, 1024)[None], cfg)
-    assert _last_path(L) == 2
+    assert _last_path(L) == 3
     hip.encode_batch(gi.ct_phantom(3, 64)[None], cfg)   # one tile only: not a tiled shape -> generic kernel
     assert _last_path(L) == 0
 
 
-def test_pipeline_signed_and_flag_variants(hip):
-    """The staged pipeline with int16 input (segmentation sees signed values), segmentation off and EOF handling,
-    against the oracle, on 512x512."""
+@pytest.mark.parametrize("tile, ran", [(4, 3), (3, 1)])
+def test_pipeline_signed_and_flag_variants(hip, tile, ran):
+    """The streaming kernel and the staged pipeline with int16 input (segmentation sees signed values), segmentation off
+    and EOF handling, against the oracle, on 512x512."""
     from oracle import oracle
     from cct_hip import _ffi
     L = _ffi.lib()
@@ -499,16 +501,20 @@ def test_pipeline_signed_and_flag_variants(hip):
     rng = np.random.default_rng(5)
     base = gi.ct_phantom(61).astype(np.int32)
     signed = (base - 1000 + rng.integers(-30, 30, size=base.shape)).astype(np.int16)
-    f = hip.encode_batch(signed[None], cfg)[0]
-    assert _last_path(L) == 1
-    assert f == oracle.encode(signed)
-    cfg2 = hip.default_config()
-    cfg2["encoder"]["transforms"]["segmentation"] = False
-    img = gi.ct_phantom(62)
-    f2 = hip.encode_batch(img[None], cfg2)[0]
-    assert _last_path(L) == 1
-    assert f2 == oracle.encode(img, segmentation=False)
-    assert hip.decode_batch([f2], cfg2)[0].tobytes() == img.tobytes()
+    _ffi.check(L.cct_set_option(b"tile_path", tile))
+    try:
+        f = hip.encode_batch(signed[None], cfg)[0]
+        assert _last_path(L) == ran
+        assert f == oracle.encode(signed)
+        cfg2 = hip.default_config()
+        cfg2["encoder"]["transforms"]["segmentation"] = False
+        img = gi.ct_phantom(62)
+        f2 = hip.encode_batch(img[None], cfg2)[0]
+        assert _last_path(L) == ran
+        assert f2 == oracle.encode(img, segmentation=False)
+        assert hip.decode_batch([f2], cfg2)[0].tobytes() == img.tobytes()
+    finally:
+        _ffi.check(L.cct_set_option(b"tile_path", 1))
 
 
 def test_config4_1024_square_batch(hip):
