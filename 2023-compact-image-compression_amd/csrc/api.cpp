@@ -145,6 +145,7 @@ struct Context {
 	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths (the streaming kernel wherever it applies), 4 the
 	                    // streaming kernel (encode_stream.hip), 3 the four-kernel pipeline (encode_pipe.hip), 2 the
 	                    // one-workgroup-per-slice tile kernel, 0 the generic LUT-gather kernel
+	int stream_tpg = STREAM_TPG;  // tuning option "stream_tpg": tiles per workgroup of the streaming kernel (1, 2, 4)
 	int pipe_tpw = 0, pipe_timing = 0;  // tuning options "pipe_tpw", "pipe_timing" (then "pipe_us_k1/k2/k3" hold the last kernel times)
 	float pipe_us[4] = {0, 0, 0, 0};
 	int last_path = -1; // read-only option "last_encode_path": which stage (i) implementation the last encode used (0 generic, 1 pipeline, 2 tile kernel, 3 streaming kernel)
@@ -699,17 +700,21 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 	// applies; 4 forces it, 3 the four-kernel pipeline of round 2, 2 the one-workgroup-per-slice tile kernel of round 1,
 	// 0 the generic table-gather kernel.
 	const bool pipe_ok = tb && tb->tiled && tb->pipe && NB <= PIPE_MAX_NB && !g_ctx.dbg_skip;
-	const int gps = tb ? (tb->n_tiles + STREAM_TPG - 1) / STREAM_TPG : 0;
-	if (pipe_ok && gps <= STREAM_MAX_GPS && (g_ctx.use_tiles == 1 || g_ctx.use_tiles == 4)) {
+	const int tpg = g_ctx.stream_tpg;
+	const int gps = tb ? (tb->n_tiles + tpg - 1) / tpg : 0;
+	if (pipe_ok && (g_ctx.use_tiles == 1 || g_ctx.use_tiles == 4)) {
 		if ((rc = E.e_pairrec.ensure((size_t)n * (NB / 2) * PIPE_PAIR_REC))) return rc;
 		if ((rc = E.e_hand.ensure(stream_ws_bytes(n, gps)))) return rc;
 		StreamArgs sa{};
 		sa.e = a;
 		sa.tiles = tb->tiles; sa.ptab = tb->d_ptab; sa.htab = tb->d_htab; sa.otab = tb->d_otab; sa.ttab = tb->d_ttab;
-		sa.n_tiles = tb->n_tiles; sa.row_pitch = width; sa.gps = gps;
+		sa.n_tiles = tb->n_tiles; sa.row_pitch = width; sa.gps = gps; sa.tpg = tpg;
+		{ static const char *dbg = getenv("CCT_STREAM_DBG"); sa.dbg = dbg ? atoi(dbg) : 0; }
 		sa.hand = (uint64_t *)E.e_hand.p; sa.ticket = (uint32_t *)(sa.hand + (size_t)n * gps * 4);
 		sa.spill_mask = (uint64_t *)E.e_lmask.p; sa.spill_idx = (uint8_t *)E.e_lcur.p; sa.pairrec = (uint8_t *)E.e_pairrec.p;
 		g_ctx.last_path = 3;
+		static const bool sstamps = getenv("CCT_STREAM_STAMPS") != nullptr;
+		if (sstamps) { HIP_TRY(launch_encode_stream(sa, n, st)); return CCT_OK; }
 		return launch_or_replay(&sa, sizeof sa, 4, [&]() { return launch_encode_stream(sa, n, st); });
 	}
 	if (pipe_ok && g_ctx.use_tiles == 3) {
@@ -1727,6 +1732,7 @@ int cct_set_option(const char *key, int value)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { if (value < 1) return fail(CCT_E_ARG, "zlib_threads < 1"); g_ctx.zlib_threads = value; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { g_ctx.use_tiles = (value >= 0 && value <= 4) ? value : 1; return CCT_OK; }
+	if (!strcmp(key, "stream_tpg")) { g_ctx.stream_tpg = (value == 1 || value == 2 || value == 4) ? value : STREAM_TPG; return CCT_OK; }
 	if (!strcmp(key, "debug_skip")) { g_ctx.dbg_skip = value; return CCT_OK; }
 	if (!strcmp(key, "pipe_tpw")) { g_ctx.pipe_tpw = value; return CCT_OK; }
 	if (!strcmp(key, "pipe_timing")) { g_ctx.pipe_timing = value; return CCT_OK; }
@@ -1750,6 +1756,7 @@ int cct_get_option(const char *key, int *value)
 	std::lock_guard<std::mutex> lk(g_mu);
 	if (!strcmp(key, "zlib_threads")) { *value = g_ctx.zlib_threads; return CCT_OK; }
 	if (!strcmp(key, "tile_path")) { *value = g_ctx.use_tiles; return CCT_OK; }
+	if (!strcmp(key, "stream_tpg")) { *value = g_ctx.stream_tpg; return CCT_OK; }
 	if (!strcmp(key, "last_encode_path")) { *value = g_ctx.last_path; return CCT_OK; }
 	if (!strncmp(key, "pipe_us_k", 9) && key[9] >= '1' && key[9] <= '4') { *value = (int)(g_ctx.pipe_us[key[9] - '1'] * 10.0f); return CCT_OK; }
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }

@@ -92,8 +92,7 @@ struct PipeTune {   // tuning runs only
 hipError_t launch_encode_pipe(const PipeArgs &pa, int n, hipStream_t s, const PipeTune *tune = nullptr);
 
 // single streaming pass (encode_stream.hip): same applicability as the pipeline; one kernel, every pixel read once
-constexpr int STREAM_TPG = 4;       // tiles per group = waves per workgroup
-constexpr int STREAM_MAX_GPS = 64;  // groups per slice: a group collects its predecessors' totals with one lane each
+constexpr int STREAM_TPG = 4;       // default tiles per group = waves per workgroup (1, 2 or 4: option "stream_tpg")
 struct StreamArgs {
 	EncArgs e;
 	PipeTiles tiles;
@@ -101,7 +100,8 @@ struct StreamArgs {
 	const uint32_t *htab;        // n_orient * 32 entries of 2 dwords: the 32 block pairs that make up a tile's first 64 traversal blocks:
 	                             //   [0] as ptab[0], [1] raster offset inside the tile of the pair's 8x4-pixel region
 	const uint32_t *otab, *ttab; // as PipeArgs (ttab entry: selectors, token bytes, kept bits of the low bytes)
-	int n_tiles, row_pitch, gps; // gps: groups per slice
+	int n_tiles, row_pitch, gps, tpg; // gps: groups per slice, tpg: tiles per group
+	int dbg;                     // tuning runs only (CCT_STREAM_DBG): 1 no carry wait, 2 no look-back (results then invalid)
 	uint64_t *hand;              // n * gps * 4 hand-off words, then
 	uint32_t *ticket;            // n group tickets (one allocation: zeroed by one memset before every launch)
 	uint64_t *spill_mask;        // n * NB: candidate masks beyond the LDS list of a tile

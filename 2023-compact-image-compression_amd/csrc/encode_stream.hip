@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "cct_internal.h"
 #include "../../include/compact_hip.h"
@@ -41,33 +42,38 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define LDS(T) __attribute__((address_space(3))) T
 
-constexpr int SW = STREAM_TPG;          // waves = tiles per workgroup
-constexpr int ST = 64 * SW;             // lanes
-constexpr int NBG = 256 * SW;           // blocks of a full group
 constexpr int HALO = 64;                // look-ahead blocks after the group
 constexpr int LCAP = 64;                // list entries per wave kept in LDS (the rest spill to HBM)
-constexpr int PAIR_FAST = ST;           // meshed pairs per group handled in registers; beyond: records in HBM
-constexpr int PAIR_MAX = (NBG + HALO) / 2;
+constexpr int MAX_SW = 4;
 
-// LDS layout (bytes).  The pixel stage and, later, the payload image share the first region: the image of a group is at
-// most 32 bytes per block + one byte per meshed pair + the pairs that reach into the look-ahead (35 327) + head + EOF.
-constexpr int L_PIX = 0;                          // [-1 .. NBG + HALO) x 32
-constexpr int L_IMG_BYTES = 35392;
-constexpr int L_ROLE = L_IMG_BYTES;               // 16 + NBG + HALO
-constexpr int L_LMASK = L_ROLE + 16 + NBG + HALO + 0;  // SW x LCAP u64; later: u16 payload offset of every block
-constexpr int L_LIDX = L_LMASK + SW * LCAP * 8;   // SW x LCAP u8
-constexpr int L_PAIRS = L_LIDX + SW * LCAP;       // PAIR_MAX u16
-constexpr int L_OTAB = L_PAIRS + PAIR_MAX * 2;    // 64 dwords
-constexpr int L_TTAB = L_OTAB + 256;              // 64 dwords
-constexpr int L_MISC = L_TTAB + 256;              // 32 dwords
-constexpr int L_TOTAL = L_MISC + 128;
-static_assert(32 * (1 + NBG + HALO) <= L_IMG_BYTES, "pixel stage must fit the image region");
-static_assert(NBG * 2 <= SW * LCAP * 8, "block offsets alias the mask list");
-static_assert(L_LMASK % 16 == 0 && L_OTAB % 16 == 0 && L_MISC % 16 == 0 && L_PAIRS % 2 == 0, "alignment");
-static_assert(L_TOTAL <= 40960, "four workgroups per CU");
+// LDS layout (bytes) of a workgroup of SW waves = SW tiles.  The pixel stage and, later, the payload image share the first
+// region: the image of a group is at most 32 bytes per block + one byte per meshed pair + the pairs that reach into the
+// look-ahead + head + EOF + what the last token's ORs touch.
+template <int SW>
+struct Geo {
+	static constexpr int ST = 64 * SW;             // lanes
+	static constexpr int NBG = 256 * SW;           // blocks of a full group
+	static constexpr int PAIR_FAST = ST;           // meshed pairs per group handled in registers; beyond: records in HBM
+	static constexpr int PAIR_MAX = (NBG + HALO) / 2;
+	static constexpr int L_PIX = 0;                // [-1 .. NBG + HALO) x 32
+	static constexpr int IMG_NEED = 32 * NBG + PAIR_MAX + 32 * 63 + 16 + 1 + 16;
+	static constexpr int PIX_NEED = 32 * (1 + NBG + HALO);
+	static constexpr int L_IMG_BYTES = ((IMG_NEED > PIX_NEED ? IMG_NEED : PIX_NEED) + 15) & ~15;
+	static constexpr int L_ROLE = L_IMG_BYTES;               // 16 + NBG + HALO
+	static constexpr int L_LMASK = L_ROLE + 16 + NBG + HALO; // SW x LCAP u64; later: u16 payload offset of every block
+	static constexpr int L_LIDX = L_LMASK + SW * LCAP * 8;   // SW x LCAP u8
+	static constexpr int L_PAIRS = L_LIDX + SW * LCAP;       // PAIR_MAX u16
+	static constexpr int L_OTAB = L_PAIRS + PAIR_MAX * 2;    // 64 dwords
+	static constexpr int L_TTAB = L_OTAB + 256;              // 64 dwords
+	static constexpr int L_MISC = L_TTAB + 256;              // 32 dwords
+	static constexpr int L_TOTAL = L_MISC + 128;
+	static_assert(NBG * 2 <= SW * LCAP * 8, "block offsets alias the mask list");
+	static_assert(L_LMASK % 16 == 0 && L_OTAB % 16 == 0 && L_MISC % 16 == 0 && L_PAIRS % 2 == 0, "alignment");
+};
+static_assert(Geo<4>::L_TOTAL <= 40960, "four workgroups of four waves per CU");
 
 enum : int {  // dwords of the misc area
-	M_TICKET = 0, M_CNT = 1 /* SW */, M_NPAIRS = 5, M_WTOT = 6 /* SW */, M_HB = 10, M_WIDE = 11, M_CARRY_LO = 12, M_CARRY_HI = 13,
+	M_TICKET = 0, M_CNT = 1 /* MAX_SW */, M_NPAIRS = 5, M_WTOT = 6 /* MAX_SW */, M_HB = 10, M_WIDE = 11, M_CARRY_LO = 12, M_CARRY_HI = 13,
 	M_LASTPX = 14, M_STATUS = 15, M_NDIFF = 16, M_BASE = 17, M_ACC_JUMP = 18, M_ACC_DIFF = 19
 };
 constexpr uint32_t WIDE_14 = 1u, WIDE_11 = 2u;   // a pixel >= 0x4000 / >= 0x0800 somewhere in the group
@@ -208,9 +214,21 @@ __device__ __forceinline__ void hand_store(uint64_t *p, uint64_t v) { __hip_atom
 __device__ __forceinline__ uint64_t hand_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr uint32_t SPIN_LIMIT = 1u << 22;   // polls (about a microsecond each) before a wait gives up with CCT_ST_INTERNAL
 
-template <bool SGN>
-__global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
+// diagnostic build only (CCT_STREAM_STAMPS=1): shader clock at every phase boundary, per wave, to a buffer of their own
+#define STAMP(k) do { if (STAMPS) { __builtin_amdgcn_sched_barrier(0); st_[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+constexpr int N_STAMPS = 16;
+
+template <int SW, bool SGN, bool STAMPS>
+__global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t *stamps)
 {
+	using G = Geo<SW>;
+	constexpr int ST = G::ST, NBG = G::NBG, PAIR_FAST = G::PAIR_FAST;
+	constexpr int L_PIX = G::L_PIX, L_IMG_BYTES = G::L_IMG_BYTES, L_ROLE = G::L_ROLE, L_LMASK = G::L_LMASK, L_LIDX = G::L_LIDX;
+	constexpr int L_PAIRS = G::L_PAIRS, L_OTAB = G::L_OTAB, L_TTAB = G::L_TTAB, L_MISC = G::L_MISC, L_TOTAL = G::L_TOTAL;
+	uint64_t st_[N_STAMPS] = {0};
+	uint64_t rt0_ = 0;
+	if (STAMPS) { rt0_ = __builtin_amdgcn_s_memrealtime(); }
+	STAMP(0);
 	__shared__ __attribute__((aligned(16))) uint8_t smem[L_TOTAL];
 	LDS(uint8_t) *lds = (LDS(uint8_t) *)smem;
 	LDS(uint8_t) *pix0 = lds + L_PIX + 32;                      // block b at pix0 + 32 b (b = -1: the pixel before the group)
@@ -226,7 +244,9 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int NT = a.n_tiles, NB = a.e.NB, N = a.e.N, gps = a.gps, pitch = a.row_pitch;
-	const int sl = blockIdx.x / gps;
+	// consecutive workgroups belong to different slices: the groups of one slice start a whole round of slices apart, so a
+	// group's predecessors are well ahead of it when it asks for their carry and totals
+	const int sl = blockIdx.x % (gridDim.x / gps);
 	const bool seg = (a.e.flags & CCT_FLAG_SEGMENTATION) != 0;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 
@@ -237,6 +257,7 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 	if (tid >= 1 && tid < 32) misc[tid] = 0u;
 	if (tid == 0) misc[M_TICKET] = atomicAdd(a.ticket + sl, 1u);
 	__syncthreads();
+	STAMP(1);
 	const int g = (int)misc[M_TICKET];
 	const int t0 = g * SW;
 	const int ntg = min(SW, NT - t0);                 // tiles of this group
@@ -308,7 +329,9 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		const uint32_t wd = (__any((orall & 0xC000C000u) != 0) ? WIDE_14 : 0u) | (__any((orall & 0xF800F800u) != 0) ? WIDE_11 : 0u);
 		if (wd && lane == 0) lds_or(&misc[M_WIDE], wd);
 	}
+	STAMP(2);
 	__syncthreads();
+	STAMP(3);
 	const uint32_t gw = misc[M_WIDE];
 	const bool wide = SGN || (gw & WIDE_14) != 0;     // exact (unpacked) arithmetic for the whole group
 	const bool big = (gw & WIDE_11) != 0;             // a delta outside [-2047, 2048] needs a pixel >= 2048
@@ -369,6 +392,18 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		bal[s] = __ballot(difficult);
 	}
 
+	// No difficult block among the group's last 64 blocks: none of them can lead a pair, so nothing of the next group is
+	// taken and the group ends with its last block emitted alone -- the next group can be told right away
+	const bool last_group = g == gps - 1;
+	bool carry_out_done = false;
+	if (wave == SW - 1 && !last_group && bal[3] == 0) {
+		if (lane == 0) {
+			hand_store(&hand[g].carry, H_VALID);
+			hand_store(&hand[g].lastpx, (uint64_t) * (const LDS(uint16_t) *)(pix0 + 32 * (nbg - 1) + 30) | H_VALID);
+		}
+		carry_out_done = true;
+	}
+	STAMP(4);
 	// ---- candidate fit masks of the wave's difficult blocks (cluster.py:110-158); entries with an empty mask are dropped:
 	// such a block can neither take a partner nor change the state of the walk
 	uint32_t cnt = 0;
@@ -442,7 +477,9 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		}
 	}
 	if (lane == 0) misc[M_CNT + wave] = cnt;
+	STAMP(5);
 	__syncthreads();
+	STAMP(6);
 
 	// ---- resolve: greedy first fit per island (two listed blocks more than 63 apart cannot influence each other)
 	const LDS(uint32_t) *cw_ = misc + M_CNT;     // entries listed per wave (tile)
@@ -513,6 +550,7 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		if (head && !(e0 == 0 && head_deferred)) walk(w, r, 0ull);
 	}
 	__syncthreads();
+	STAMP(7);
 	// does the deferred island reach the blocks that decide what this group hands on?
 	bool chain = false;
 	if (head_deferred) {
@@ -522,7 +560,6 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		locate(hb - 1, w, r);
 		chain = idx_of(w, r) + 63u >= (uint32_t)(nbg - 64);
 	}
-	const bool last_group = g == gps - 1;
 	auto publish_carry = [&]() {  // one whole wave
 		const uint64_t cm = __ballot(lane < 63 && roles[nbg + lane] != 0);
 		uint32_t px = 0;
@@ -535,8 +572,8 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 			hand_store(&hand[g].lastpx, (uint64_t)px | H_VALID);
 		}
 	};
-	if (wave == SW - 1 && !last_group && !(head_deferred && chain)) publish_carry();
-	if (wave == 0 && g > 0) {
+	if (wave == SW - 1 && !last_group && !carry_out_done && !(head_deferred && chain)) publish_carry();
+	if (wave == 0 && g > 0 && !(a.dbg & 1)) {
 		uint64_t v = 0;
 		uint32_t spins = 0;
 		bool ok = lane >= 2;
@@ -557,8 +594,10 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 			walk(w, 0u, carry >> (idx_of(w, 0u) & 63u));
 		}
 	}
+	STAMP(8);
 	__syncthreads();
-	if (wave == SW - 1 && !last_group && head_deferred && chain) publish_carry();
+	STAMP(9);
+	if (wave == SW - 1 && !last_group && !carry_out_done && head_deferred && chain) publish_carry();
 	const uint32_t lastpx_in = misc[M_LASTPX];            // 0 for the first group: the slice starts from pixel value 0
 
 	// last pixel written before block b's group in the final order (b alone or a leader)
@@ -625,6 +664,7 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		}
 	}
 	__syncthreads();
+	STAMP(10);
 
 	// ---- token bytes of every block along the final order, offsets inside the tile
 	uint32_t off[4], run = 0;
@@ -663,6 +703,7 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 	}
 	if (__any(q7) && lane == 0) lds_or(&misc[M_STATUS], CCT_ST_Q7);
 	__syncthreads();
+	STAMP(11);
 	uint32_t tilebase = 0, gtot = 0;
 #pragma unroll
 	for (int v = 0; v < SW; v++) { const uint32_t t = misc[M_WTOT + v]; if (v < wave) tilebase += t; gtot += t; }
@@ -676,21 +717,26 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 	if (wave == 0) {
 		// hand on the totals, then collect the predecessors' (at most 63 of them: one lane each)
 		if (lane == 0) hand_store(&hand[g].total, H_VALID | (uint64_t)gtot | (uint64_t)npairs << 24 | (uint64_t)misc[M_NDIFF] << 40);
-		uint64_t v = 0;
-		bool ok = lane >= g;
-		uint32_t spins = 0;
-		while (!__all(ok)) {
-			if (!ok) { v = hand_load(&hand[lane].total); ok = (v & H_VALID) != 0; }
-			if (++spins > SPIN_LIMIT) { if (lane == 0) lds_or(&misc[M_STATUS], CCT_ST_INTERNAL); break; }
-			if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
+		uint32_t bytes = 0, nj = 0, ndf = 0, spins = 0;
+		if (a.dbg & 2) bytes = (uint32_t)g * (uint32_t)(NBG * 20);
+		else for (int c0 = 0; c0 < g; c0 += 64) {   // 64 predecessors at a time, one lane each
+			uint64_t v = 0;
+			bool ok = c0 + lane >= g;
+			while (!__all(ok)) {
+				if (!ok) { v = hand_load(&hand[c0 + lane].total); ok = (v & H_VALID) != 0; }
+				if (++spins > SPIN_LIMIT) { if (lane == 0) lds_or(&misc[M_STATUS], CCT_ST_INTERNAL); break; }
+				if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
+			}
+			if (c0 + lane >= g) v = 0;
+			bytes += rdlane(wave_incl_scan((uint32_t)v & 0xFFFFFFu), 63);
+			nj += rdlane(wave_incl_scan((uint32_t)(v >> 24) & 0xFFFFu), 63);
+			ndf += rdlane(wave_incl_scan((uint32_t)(v >> 40) & 0xFFFFu), 63);
 		}
-		if (lane >= g) v = 0;
-		const uint32_t bytes = rdlane(wave_incl_scan((uint32_t)v & 0xFFFFFFu), 63);
-		const uint32_t nj = rdlane(wave_incl_scan((uint32_t)(v >> 24) & 0xFFFFu), 63);
-		const uint32_t ndf = rdlane(wave_incl_scan((uint32_t)(v >> 40) & 0xFFFFu), 63);
 		if (lane == 0) { misc[M_BASE] = bytes; misc[M_ACC_JUMP] = nj; misc[M_ACC_DIFF] = ndf; }
 	}
+	STAMP(12);
 	__syncthreads();
+	STAMP(13);
 
 	// ---- the pixel stage becomes the payload image
 	const uint32_t base = misc[M_BASE];
@@ -726,6 +772,7 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 	}
 	if (eofb && tid == 0) stg[head + gtot] = (uint8_t)a.e.eof;   // core.py:329-330 (nothing else writes this byte)
 	__syncthreads();
+	STAMP(14);
 
 	// ---- flush: whole 16-byte chunks with one store, the two ends shared with the neighbouring groups byte by byte
 	uint32_t stat = misc[M_STATUS];
@@ -763,9 +810,44 @@ __global__ void __launch_bounds__(ST, SW) stream_kernel(StreamArgs a)
 		}
 	}
 	if (stat && tid == 0) atomicOr(a.e.status + sl, stat);   // the launch zeroes status[]
+	if (STAMPS && lane == 0 && stamps) {
+		st_[15] = __builtin_amdgcn_s_memtime();
+		uint64_t *o = stamps + ((size_t)blockIdx.x * SW + wave) * (N_STAMPS + 2);
+		for (int k = 0; k < N_STAMPS; k++) o[k] = st_[k];
+		o[N_STAMPS] = rt0_; o[N_STAMPS + 1] = __builtin_amdgcn_s_memrealtime();
+	}
 }
 
 }  // namespace
+
+static void report_stream_stamps(const uint64_t *d_buf, size_t nwaves)
+{
+	const int W = N_STAMPS + 2;
+	std::vector<uint64_t> h(nwaves * W);
+	if (hipMemcpy(h.data(), d_buf, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+	static const char *const name[N_STAMPS - 1] = {"tables+ticket", "loads+permute", "barrier 1", "analysis", "masks", "barrier 2", "resolve", "carry wait",
+	                                               "barrier 4", "pairs", "sizes", "totals+lookback", "barrier 7", "zero+emit", "flush"};
+	double sum[N_STAMPS] = {0};
+	std::vector<double> life, start, endt;
+	uint64_t t0 = ~0ull;
+	for (size_t i = 0; i < nwaves; i++) if (h[i * W + N_STAMPS]) t0 = std::min(t0, h[i * W + N_STAMPS]);
+	size_t m = 0;
+	for (size_t i = 0; i < nwaves; i++) {
+		const uint64_t *o = h.data() + i * W;
+		if (!o[N_STAMPS]) continue;
+		m++;
+		for (int k = 0; k + 1 < N_STAMPS; k++) sum[k] += (double)(o[k + 1] - o[k]);
+		life.push_back((o[N_STAMPS + 1] - o[N_STAMPS]) * 0.01); start.push_back((o[N_STAMPS] - t0) * 0.01); endt.push_back((o[N_STAMPS + 1] - t0) * 0.01);
+	}
+	if (!m) return;
+	double all = 0, lf = 0;
+	for (int k = 0; k + 1 < N_STAMPS; k++) all += sum[k];
+	for (double v : life) lf += v;
+	std::sort(life.begin(), life.end()); std::sort(start.begin(), start.end()); std::sort(endt.begin(), endt.end());
+	fprintf(stderr, "[stream stamps] %zu waves, %.0f shader cycles per wave, life us p50 %.1f p90 %.1f max %.1f, mean concurrency %.0f waves, starts p50 %.1f p100 %.1f, ends p100 %.1f\n",
+	        m, all / m, life[m / 2], life[m * 9 / 10], life[m - 1], lf / endt[m - 1], start[m / 2], start[m - 1], endt[m - 1]);
+	for (int k = 0; k + 1 < N_STAMPS; k++) fprintf(stderr, "    %-16s %8.0f cycles  %5.1f %%\n", name[k], sum[k] / m, 100.0 * sum[k] / all);
+}
 
 hipError_t launch_encode_stream(const StreamArgs &sa, int n, hipStream_t s)
 {
@@ -774,8 +856,34 @@ hipError_t launch_encode_stream(const StreamArgs &sa, int n, hipStream_t s)
 	if (e != hipSuccess) return e;
 	e = hipMemsetAsync(sa.e.status, 0, (size_t)n * sizeof(uint32_t), s);  // every group ORs its bits in
 	if (e != hipSuccess) return e;
-	if (sa.e.flags & CCT_FLAG_SIGNED_SEG) hipLaunchKernelGGL(stream_kernel<true>, dim3(n * sa.gps), dim3(ST), 0, s, sa);
-	else hipLaunchKernelGGL(stream_kernel<false>, dim3(n * sa.gps), dim3(ST), 0, s, sa);
+	const bool sg = (sa.e.flags & CCT_FLAG_SIGNED_SEG) != 0;
+	static const bool stamps_on = getenv("CCT_STREAM_STAMPS") != nullptr;
+	uint64_t *d_st = nullptr;
+	const size_t nw = (size_t)n * sa.gps * sa.tpg;
+	if (stamps_on) {
+		if (hipMalloc(&d_st, nw * (N_STAMPS + 2) * 8) != hipSuccess) return hipErrorOutOfMemory;
+		(void)hipMemset(d_st, 0, nw * (N_STAMPS + 2) * 8);
+	}
+#define CCT_LAUNCH(SWV)                                                                                                          \
+	do {                                                                                                                           \
+		if (stamps_on) {                                                                                                             \
+			if (sg) hipLaunchKernelGGL((stream_kernel<SWV, true, true>), dim3(n * sa.gps), dim3(64 * SWV), 0, s, sa, d_st);          \
+			else hipLaunchKernelGGL((stream_kernel<SWV, false, true>), dim3(n * sa.gps), dim3(64 * SWV), 0, s, sa, d_st);           \
+		} else if (sg) hipLaunchKernelGGL((stream_kernel<SWV, true, false>), dim3(n * sa.gps), dim3(64 * SWV), 0, s, sa, d_st);    \
+		else hipLaunchKernelGGL((stream_kernel<SWV, false, false>), dim3(n * sa.gps), dim3(64 * SWV), 0, s, sa, d_st);            \
+	} while (0)
+	switch (sa.tpg) {
+	case 1: CCT_LAUNCH(1); break;
+	case 2: CCT_LAUNCH(2); break;
+	case 4: CCT_LAUNCH(4); break;
+	default: return hipErrorInvalidValue;
+	}
+#undef CCT_LAUNCH
+	if (stamps_on) {
+		(void)hipStreamSynchronize(s);
+		report_stream_stamps(d_st, nw);
+		(void)hipFree(d_st);
+	}
 	return hipGetLastError();
 }
 

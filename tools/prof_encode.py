@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--slices", type=int, default=256)
+    ap.add_argument("--tpg", default="", help="tiles per workgroup of the streaming kernel for every path-4 run (e.g. 1,2,4)")
     ap.add_argument("--real", action="store_true", help="use the two real CT slices (tests/golden) instead of phantoms")
     args = ap.parse_args()
     n, w = args.slices, args.size
@@ -48,8 +49,16 @@ def main():
     params = codec_params(cct_hip.default_config(), np.uint16)
     e0, e1 = Event(), Event()
     ref = None
+    runs = []
     for path in [int(x) for x in args.paths.split(",")]:
+        if path == 4 and args.tpg:
+            runs += [(4, int(t)) for t in args.tpg.split(",")]
+        else:
+            runs.append((path, 0))
+    for path, tpg in runs:
         L.cct_set_option(b"tile_path", path)
+        if tpg:
+            L.cct_set_option(b"stream_tpg", tpg)
         ts = []
         for it in range(args.reps + 3):
             e0.record()
@@ -63,7 +72,7 @@ def main():
             ref = tot
         px = n * w * w
         med = ts[len(ts) // 2]
-        print(f"path {path}: us min {ts[0]:8.1f} med {med:8.1f} max {ts[-1]:8.1f}   read {2 * px / med / 1e3:7.1f} GB/s"
+        print(f"path {path}{'/' + str(tpg) if tpg else ''}: us min {ts[0]:8.1f} med {med:8.1f} max {ts[-1]:8.1f}   read {2 * px / med / 1e3:7.1f} GB/s"
               f" = {2 * px / med / 1e3 / 8000:.3f} of 8 TB/s   payload {tot} B {'(same)' if tot == ref else '(DIFFERS)'}", flush=True)
     L.cct_set_option(b"tile_path", 1)
 
