@@ -711,7 +711,7 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 		sa.n_tiles = tb->n_tiles; sa.row_pitch = width; sa.gps = gps; sa.tpg = tpg;
 		{ static const char *dbg = getenv("CCT_STREAM_DBG"); sa.dbg = dbg ? atoi(dbg) : 0; }
 		sa.hand = (uint64_t *)E.e_hand.p; sa.ticket = (uint32_t *)(sa.hand + (size_t)n * gps * 4);
-		sa.spill_mask = (uint64_t *)E.e_lmask.p; sa.spill_idx = (uint8_t *)E.e_lcur.p; sa.pairrec = (uint8_t *)E.e_pairrec.p;
+		sa.spill_mask = (uint64_t *)E.e_lmask.p; sa.spill_idx = (uint16_t *)E.e_lidx.p; sa.pairrec = (uint8_t *)E.e_pairrec.p;
 		g_ctx.last_path = 3;
 		static const bool sstamps = getenv("CCT_STREAM_STAMPS") != nullptr;
 		if (sstamps) { HIP_TRY(launch_encode_stream(sa, n, st)); return CCT_OK; }

@@ -105,7 +105,7 @@ struct StreamArgs {
 	uint64_t *hand;              // n * gps * 4 hand-off words, then
 	uint32_t *ticket;            // n group tickets (one allocation: zeroed by one memset before every launch)
 	uint64_t *spill_mask;        // n * NB: candidate masks beyond the LDS list of a tile
-	uint8_t *spill_idx;          // n * NB: their blocks
+	uint16_t *spill_idx;         // n * NB: their blocks
 	uint8_t *pairrec;            // n * (NB / 2) * PIPE_PAIR_REC: meshed pairs beyond one per lane
 };
 inline size_t stream_ws_bytes(int n, int gps) { return ((size_t)n * gps * 32 + (size_t)n * 4 + 15) & ~(size_t)15; }

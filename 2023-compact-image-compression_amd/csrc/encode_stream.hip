@@ -61,12 +61,12 @@ struct Geo {
 	static constexpr int L_IMG_BYTES = ((IMG_NEED > PIX_NEED ? IMG_NEED : PIX_NEED) + 15) & ~15;
 	static constexpr int L_ROLE = L_IMG_BYTES;               // 16 + NBG + HALO
 	static constexpr int L_LMASK = L_ROLE + 16 + NBG + HALO; // SW x LCAP u64; later: u16 payload offset of every block
-	static constexpr int L_LIDX = L_LMASK + SW * LCAP * 8;   // SW x LCAP u8
-	static constexpr int L_PAIRS = L_LIDX + SW * LCAP;       // PAIR_MAX u16
+	static constexpr int L_LIDX = L_LMASK + SW * LCAP * 8;   // SW x LCAP u16
+	static constexpr int L_PAIRS = L_LIDX + SW * LCAP * 2;   // PAIR_MAX u16
 	static constexpr int L_OTAB = L_PAIRS + PAIR_MAX * 2;    // 64 dwords
 	static constexpr int L_TTAB = L_OTAB + 256;              // 64 dwords
-	static constexpr int L_MISC = L_TTAB + 256;              // 32 dwords
-	static constexpr int L_TOTAL = L_MISC + 128;
+	static constexpr int L_MISC = L_TTAB + 256;              // 32 dwords, then the difficult-block ballots of the SW x 4 slots
+	static constexpr int L_TOTAL = L_MISC + 128 + MAX_SW * 4 * 8;
 	static_assert(NBG * 2 <= SW * LCAP * 8, "block offsets alias the mask list");
 	static_assert(L_LMASK % 16 == 0 && L_OTAB % 16 == 0 && L_MISC % 16 == 0 && L_PAIRS % 2 == 0, "alignment");
 };
@@ -114,6 +114,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 	return v;
 }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)  // a value every lane holds, as a scalar
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+}
 
 // Rows 0..3 of a 4x4 block as (columns 0-1, columns 2-3) dwords -> its 16 pixels in traversal order (see
 // build_pipe_tables in api.cpp for the structure this relies on and verifies).
@@ -235,7 +239,8 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	LDS(uint8_t) *roles = lds + L_ROLE + 16;                    // 0 alone, 1..63 leader (jump), >= 0x80 partner
 	LDS(uint64_t) *lmask = (LDS(uint64_t) *)(lds + L_LMASK);
 	LDS(uint16_t) *boff = (LDS(uint16_t) *)(lds + L_LMASK);     // after the resolve
-	LDS(uint8_t) *lidx = lds + L_LIDX;
+	LDS(uint16_t) *lidx = (LDS(uint16_t) *)(lds + L_LIDX);
+	LDS(uint64_t) *dbal = (LDS(uint64_t) *)(lds + L_MISC + 128);
 	LDS(uint16_t) *pairs = (LDS(uint16_t) *)(lds + L_PAIRS);
 	LDS(uint32_t) *otab = (LDS(uint32_t) *)(lds + L_OTAB);
 	LDS(uint8_t) *ttab = lds + L_TTAB;
@@ -266,6 +271,10 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	const bool has_next = t0 + ntg < NT;              // a look-ahead exists
 	const bool active = wave < ntg;
 	Hand *hand = reinterpret_cast<Hand *>(a.hand) + (size_t)sl * gps;
+	// the predecessor's carry and last pixel: asked for now, looked at after the resolve (most groups have published both
+	// long before); lanes 0 and 1 of wave 0
+	uint64_t carry_v = 0;
+	if (wave == 0 && g > 0 && lane < 2 && !(a.dbg & 1)) carry_v = hand_load(lane == 0 ? &hand[g - 1].carry : &hand[g - 1].lastpx);
 
 	// ---- HBM -> VGPR -> LDS (traversal order)
 	{
@@ -404,75 +413,96 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		carry_out_done = true;
 	}
 	STAMP(4);
-	// ---- candidate fit masks of the wave's difficult blocks (cluster.py:110-158); entries with an empty mask are dropped:
-	// such a block can neither take a partner nor change the state of the walk
+	// ---- candidate fit masks of the group's difficult blocks (cluster.py:110-158).  The waves share the work by ordinal:
+	// wave v of the ntg active ones takes the v-th quarter of the group's difficult blocks, in order (a tile full of bone
+	// would otherwise keep the other three waiting), so the per-wave lists concatenate to the ordered list the resolve walks.
+	// Entries with an empty mask are dropped: such a block can neither take a partner nor change the state of the walk.
+	if (lane == 0) {
+#pragma unroll
+		for (int s = 0; s < 4; s++) dbal[wave * 4 + s] = bal[s];
+	}
+	__syncthreads();
 	uint32_t cnt = 0;
 	if (active && seg) {
-		LDS(uint8_t) *my_idx = lidx + wave * LCAP;
+		LDS(uint16_t) *my_idx = lidx + wave * LCAP;
 		LDS(uint64_t) *my_mask = lmask + wave * LCAP;
-		uint8_t *sp_idx = a.spill_idx + (size_t)sl * NB + abs0 + 256 * wave;
+		uint16_t *sp_idx = a.spill_idx + (size_t)sl * NB + abs0 + 256 * wave;
 		uint64_t *sp_mask = a.spill_mask + (size_t)sl * NB + abs0 + 256 * wave;
-#pragma unroll
-		for (int s = 0; s < 4; s++) {
-			uint64_t bm = bal[s];
-			if (bm == 0) continue;
-			const int b = 256 * wave + 64 * s + lane;
-			const LDS(u32x4) *pp = (const LDS(u32x4) *)(pix0 + 32 * b);
-			const u32x4 v0 = pp[0], v1 = pp[1];
-			const uint32_t d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-			// thresholds of the lane's own block as block A: lane j of the evaluating step compares
-			//   B[t] - A[t] >= 65      <=>  bit 15 of B[t] - (A[t] + 65 + 0x8000)
-			//   A[t+1] - B[t] >= 65    <=>  bit 15 of (A[t+1] - 65 + 0x8000) - B[t]       (t = 15 has no successor: never)
-			uint32_t sA[8], sN[8];
+		uint32_t D = 0;
+		for (int q = 0; q < 4 * ntg; q++) D += (uint32_t)__popcll(dbal[q]);
+		D = (uint32_t)__builtin_amdgcn_readfirstlane((int)D);
+		const uint32_t lo = (uint32_t)wave * D / (uint32_t)ntg, hi = (uint32_t)(wave + 1) * D / (uint32_t)ntg;
+		// seek ordinal lo
+		int sq = 0;
+		uint64_t bm = 0;
+		if (hi > lo) {
+			uint32_t skip = lo;
+			for (;;) {
+				const uint64_t v = dbal[sq];
+				bm = uniform64(v);
+				const uint32_t c = (uint32_t)__popcll(bm);
+				if (skip < c) break;
+				skip -= c; sq++;
+			}
+			for (; skip; skip--) bm &= bm - 1;
+		}
+		for (uint32_t todo = hi - lo; todo; todo--) {
+			while (bm == 0) {
+				sq++;
+				const uint64_t v = dbal[sq];
+				bm = uniform64(v);
+			}
+			const int la = __builtin_ctzll(bm);
+			bm &= bm - 1;
+			const int ba = 64 * sq + la;                                          // block A, group index (wave-uniform)
+			const bool a_first = abs0 + ba == 0;
+			const LDS(uint8_t) *pA = pix0 + 32 * ba;
+			// every lane holds block A (one address: a broadcast read) and its own candidate B = A + lane
+			const u32x4 a0 = ((const LDS(u32x4) *)pA)[0], a1 = ((const LDS(u32x4) *)pA)[1];
+			const LDS(u32x4) *pq = (const LDS(u32x4) *)(pA + 32 * lane);
+			const u32x4 w0 = pq[0], w1 = pq[1];
+			// transitions of A including the entering one (cluster.py:110): lane t looks at pixel t
+			const int tcl = lane & 15;
+			int pt = (int)*(const LDS(uint16_t) *)(pA + 2 * tcl), pp_ = (int)*(const LDS(uint16_t) *)(pA + 2 * tcl - 2);
+			if (SGN) { pt = (int)(int16_t)pt; pp_ = (int)(int16_t)pp_; }
+			const uint32_t cur = (uint32_t)__popcll(__ballot(lane < 16 && !(a_first && lane == 0) && seg_large(pt - pp_)));
+			const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+			const uint32_t bw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+			const bool valid = lane >= 1 && abs0 + ba + lane < NB;
+			uint32_t up;
 			if (!wide) {
+				//   B[t] - A[t] >= 65      <=>  bit 15 of B[t] - (A[t] + 65 + 0x8000)
+				//   A[t+1] - B[t] >= 65    <=>  bit 15 of (A[t+1] - 65 + 0x8000) - B[t]       (t = 15 has no successor: never)
+				uint32_t acc = 0;
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
-					const uint32_t an = j < 7 ? __builtin_amdgcn_alignbit(d[j + 1], d[j], 16) : (d[7] >> 16);
-					sA[j] = pk_add(d[j], 0x80418041u);
-					sN[j] = pk_add(an, 0x7FBF7FBFu);
+					const uint32_t an = j < 7 ? __builtin_amdgcn_alignbit(av[j + 1], av[j], 16) : (av[7] >> 16);
+					const uint32_t r1 = pk_sub(bw[j], pk_add(av[j], 0x80418041u));
+					const uint32_t r2 = pk_sub(pk_add(an, 0x7FBF7FBFu), bw[j]);
+					acc = __builtin_amdgcn_sad_u8(perm(r2, r1, 0x07050301u) & 0x80808080u, 0u, acc);
+				}
+				up = acc >> 7;
+			} else {
+				up = 0;
+				int bprev = 0;
+#pragma unroll
+				for (int t = 0; t < 16; t++) {
+					int avv = (int)((av[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
+					if (SGN) { avv = (int)(int16_t)avv; bv = (int)(int16_t)bv; }
+					if (t > 0) up += (avv - bprev >= 65) ? 1u : 0u;
+					up += (bv - avv >= 65) ? 1u : 0u;
+					bprev = bv;
 				}
 			}
-			while (bm) {
-				const int la = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bm));
-				bm &= bm - 1;
-				const int ba = 256 * wave + 64 * s + la;                            // block A, group index (wave-uniform)
-				const uint32_t cur = (rdlane(info[s], la) >> 21) & 31u;
-				const LDS(u32x4) *pq = (const LDS(u32x4) *)(pix0 + 32 * (ba + lane));
-				const u32x4 w0 = pq[0], w1 = pq[1];
-				const uint32_t bw[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-				const bool valid = lane >= 1 && abs0 + ba + lane < NB;
-				uint32_t up;
-				if (!wide) {
-					uint32_t acc = 0;
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						const uint32_t r1 = pk_sub(bw[j], rdlane(sA[j], la));
-						const uint32_t r2 = pk_sub(rdlane(sN[j], la), bw[j]);
-						acc = __builtin_amdgcn_sad_u8(perm(r2, r1, 0x07050301u) & 0x80808080u, 0u, acc);
-					}
-					up = acc >> 7;
-				} else {
-					up = 0;
-					int bprev = 0;
-#pragma unroll
-					for (int t = 0; t < 16; t++) {
-						int av = (int)((rdlane(d[t >> 1], la) >> ((t & 1) * 16)) & 0xFFFFu), bv = (int)((bw[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
-						if (SGN) { av = (int)(int16_t)av; bv = (int)(int16_t)bv; }
-						if (t > 0) up += (av - bprev >= 65) ? 1u : 0u;
-						up += (bv - av >= 65) ? 1u : 0u;
-						bprev = bv;
-					}
+			// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 of the slice wraps: it always fits
+			const bool fit = valid && (a_first ? true : ((up + 1u) < (cur - 2u)));
+			const uint64_t mk = __ballot(fit);
+			if (mk) {
+				if (lane == 0) {
+					if (cnt < (uint32_t)LCAP) { my_idx[cnt] = (uint16_t)ba; my_mask[cnt] = mk; }
+					else { sp_idx[cnt] = (uint16_t)ba; sp_mask[cnt] = mk; }
 				}
-				// cluster.py:153,158: up + 1 < current_delta - 2 in uint32; block 0 of the slice wraps: it always fits
-				const bool fit = valid && (abs0 + ba == 0 ? true : ((up + 1u) < (cur - 2u)));
-				const uint64_t mk = __ballot(fit);
-				if (mk) {
-					if (lane == 0) {
-						if (cnt < (uint32_t)LCAP) { my_idx[cnt] = (uint8_t)(64 * s + la); my_mask[cnt] = mk; }
-						else { sp_idx[cnt] = (uint8_t)(64 * s + la); sp_mask[cnt] = mk; }
-					}
-					cnt++;
-				}
+				cnt++;
 			}
 		}
 	}
@@ -482,14 +512,17 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	STAMP(6);
 
 	// ---- resolve: greedy first fit per island (two listed blocks more than 63 apart cannot influence each other)
-	const LDS(uint32_t) *cw_ = misc + M_CNT;     // entries listed per wave (tile)
+	uint32_t cwr[MAX_SW];                         // entries listed per wave
+#pragma unroll
+	for (int v = 0; v < MAX_SW; v++) cwr[v] = v < SW ? misc[M_CNT + v] : 0u;
+	auto cw_ = [&](uint32_t w) -> uint32_t { return w == 0 ? cwr[0] : (w == 1 ? cwr[1] : (w == 2 ? cwr[2] : cwr[3])); };
 	uint32_t E = 0;
 #pragma unroll
-	for (int v = 0; v < SW; v++) E += cw_[v];
+	for (int v = 0; v < SW; v++) E += cwr[v];
 	auto idx_of = [&](uint32_t w, uint32_t r) -> uint32_t {
 		uint32_t k;
 		if (r < (uint32_t)LCAP) k = lidx[w * LCAP + r]; else k = a.spill_idx[(size_t)sl * NB + abs0 + 256 * w + r];
-		return 256u * w + k;
+		return k;
 	};
 	auto mask_of = [&](uint32_t w, uint32_t r) -> uint64_t {
 		uint64_t m;
@@ -499,11 +532,11 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	auto locate = [&](uint32_t e, uint32_t &w, uint32_t &r) {  // entry e of the concatenated lists
 		w = 0; r = e;
 #pragma unroll
-		for (int v = 0; v < SW - 1; v++) if (w == (uint32_t)v && r >= cw_[v]) { r -= cw_[v]; w++; }
+		for (int v = 0; v < SW - 1; v++) if (w == (uint32_t)v && r >= cwr[v]) { r -= cwr[v]; w++; }
 	};
 	auto next_of = [&](uint32_t &w, uint32_t &r) -> bool {       // the entry after (w, r)
 		r++;
-		while (w < (uint32_t)SW && r >= cw_[w]) { w++; r = 0; }
+		while (w < (uint32_t)SW && r >= cw_(w)) { w++; r = 0; }
 		return w < (uint32_t)SW;
 	};
 	auto walk = [&](uint32_t w, uint32_t r, uint64_t cw) {
@@ -533,7 +566,7 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	bool head_deferred = false;
 	if (E) {
 		uint32_t w0_ = 0, r0_ = 0;
-		while (cw_[w0_] == 0) w0_++;
+		while (cw_(w0_) == 0) w0_++;
 		head_deferred = g > 0 && idx_of(w0_, r0_) <= 62u;
 	}
 	for (uint32_t e0 = tid; e0 < E; e0 += ST) {
@@ -574,9 +607,9 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	};
 	if (wave == SW - 1 && !last_group && !carry_out_done && !(head_deferred && chain)) publish_carry();
 	if (wave == 0 && g > 0 && !(a.dbg & 1)) {
-		uint64_t v = 0;
+		uint64_t v = carry_v;
 		uint32_t spins = 0;
-		bool ok = lane >= 2;
+		bool ok = lane >= 2 || (v & H_VALID) != 0;
 		const uint64_t *src = lane == 0 ? &hand[g - 1].carry : &hand[g - 1].lastpx;
 		while (!__all(ok)) {
 			if (!ok) { v = hand_load(src); ok = (v & H_VALID) != 0; }
@@ -590,7 +623,7 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		if (lane == 0) { misc[M_LASTPX] = lpx; misc[M_CARRY_LO] = c_lo; misc[M_CARRY_HI] = c_hi; }
 		if (head_deferred && lane == 0) {
 			uint32_t w = 0;
-			while (cw_[w] == 0) w++;
+			while (cw_(w) == 0) w++;
 			walk(w, 0u, carry >> (idx_of(w, 0u) & 63u));
 		}
 	}
