@@ -1,7 +1,8 @@
 """Multi-GPU sharding of a slice corpus: one process per GPU, contiguous slice ranges, and the
-path's only exchange step -- an all-gather of per-slice compressed sizes (RCCL over xGMI when
-the process group is "nccl"; gloo on CPU for tests).  No pixel or payload byte crosses GPUs:
-slices are independent units (the reference treats them so too, scripts/evaluate.py:107-119).
+path's only exchange step -- an all-gather of per-slice compressed sizes over RCCL / xGMI, reached through the
+library's C ABI (cct_comm_*; no PyTorch here -- the torch.distributed twin used by the gloo test lives in
+tests/gloo_gather.py).  No pixel or payload byte crosses GPUs: slices are independent units (the reference treats
+them so too, scripts/evaluate.py:107-119).
 """
 import ctypes as C
 import os
@@ -21,43 +22,6 @@ def shard_range(n_total, rank, world):
     return lo, lo + per + (1 if rank < extra else 0)
 
 
-def gather_sizes(local_sizes, dist=None, local_rank=0, counts=None):
-    """All ranks' per-slice compressed sizes, in global slice order.
-
-    local_sizes: uint32 array of this rank's sizes.  `dist` is torch.distributed (initialised) or
-    None for single-process runs.  Ranks may own different counts (last shard shorter): arrays are
-    padded to the longest shard for the collective and trimmed afterwards.
-    """
-    local_sizes = np.ascontiguousarray(local_sizes, dtype=np.uint32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local_sizes.copy()
-    import torch
-    world = dist.get_world_size()
-    on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
-    if counts is None:
-        cnt = torch.tensor([local_sizes.size], dtype=torch.int64, device=dev)
-        all_cnt = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(all_cnt, cnt)
-        counts = [int(c.item()) for c in all_cnt]
-    width = max(counts) if counts else 0
-    buf = torch.zeros(max(width, 1), dtype=torch.int64, device=dev)
-    if local_sizes.size:
-        buf[: local_sizes.size] = torch.from_numpy(local_sizes.astype(np.int64)).to(dev)
-    out = torch.empty(world * buf.numel(), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(out, buf) if hasattr(dist, "all_gather_into_tensor") and on_gpu else \
-        _all_gather_list(dist, out, buf, world)
-    out = out.cpu().numpy().reshape(world, -1)
-    return np.concatenate([out[r, : counts[r]] for r in range(world)]).astype(np.uint32)
-
-
-def _all_gather_list(dist, out, buf, world):
-    import torch
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf)
-    out.copy_(torch.cat(parts))
-
-
 def file_offsets(all_sizes):
     """Exclusive scan of the gathered sizes: byte offset of every slice's file in the archive."""
     offs = np.zeros(len(all_sizes) + 1, dtype=np.uint64)
@@ -67,29 +31,55 @@ def file_offsets(all_sizes):
 
 # ---- RCCL through the C ABI (no PyTorch): cct_comm_* / cct_allgather_u32 ---------------------------------------
 
-def exchange_unique_id(rank, world, make_id, directory=None, key=None, timeout_s=120.0):
-    """Rank 0 creates the 128-byte communicator id (make_id()) and leaves it in a file the other ranks wait for.  The file
-    name is derived from what the launcher gives every rank alike (MASTER_PORT, the launcher's pid, TORCHELASTIC_RUN_ID),
-    so that two launches on one host do not see each other's id."""
+def rendezvous_key():
+    """What every rank of one launch knows alike and another launch on the host does not share: the rendezvous address
+    and port the launcher exports, its run id and restart count.  Only a launch that sets none of them falls back to the
+    parent's pid (ranks started by hand from one shell)."""
+    env = os.environ
+    if env.get("MASTER_PORT") or env.get("TORCHELASTIC_RUN_ID"):
+        parts = (env.get("MASTER_ADDR", "localhost"), env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
+                 env.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    else:
+        parts = ("ppid", os.getppid())
+    return "_".join(str(x).replace("/", "-").replace(":", "-") for x in parts)
+
+
+def _process_start_time():
+    try:
+        import psutil
+        return psutil.Process().create_time()
+    except Exception:  # noqa: BLE001 -- no psutil: the age check is skipped
+        return None
+
+
+def exchange_unique_id(rank, world, make_id, directory=None, key=None, timeout_s=120.0, max_age_s=5.0):
+    """Rank 0 creates the 128-byte communicator id (make_id()) and leaves it in a file the other ranks wait for
+    (rendezvous_key() names it).  A file left behind by a launch that died is not taken for this launch's id: rank 0 removes
+    whatever carries the name before it does anything slow, and the other ranks ignore a file older than their own process
+    (minus max_age_s: the ranks of a launch start together, rank 0 writes seconds later)."""
     directory = directory or os.environ.get("CCT_RENDEZVOUS_DIR", "/tmp")
-    if key is None:
-        key = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                        os.getppid()))
-    path = os.path.join(directory, f"cct_rccl_id_{key}")
+    path = os.path.join(directory, f"cct_rccl_id_{key if key is not None else rendezvous_key()}")
     if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
         blob = bytes(make_id())
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
             f.write(blob)
         os.replace(tmp, path)  # atomic: readers see nothing or all of it
         return blob, path
+    born = _process_start_time()
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as f:
-                blob = f.read()
-            if len(blob) == 128:
-                return blob, path
+            st = os.stat(path)
+            if born is None or st.st_mtime >= born - max_age_s:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == 128:
+                    return blob, path
         except OSError:
             pass
         if time.time() - t0 > timeout_s:
@@ -108,13 +98,20 @@ def comm_init(rank, world):
         return bytes(buf)
 
     blob, path = exchange_unique_id(rank, world, make_id)
-    _ffi.check(L.cct_comm_init(blob, rank, world))
-    allgather_u32(np.zeros(1, np.uint32), 1)  # everyone has read the id once this returns
-    if rank == 0:
+
+    def forget():
         try:
             os.remove(path)
         except OSError:
             pass
+
+    if rank == 0:
+        import atexit
+        atexit.register(forget)  # also when this rank dies before the first gather
+    _ffi.check(L.cct_comm_init(blob, rank, world))
+    allgather_u32(np.zeros(1, np.uint32), 1)  # everyone has read the id once this returns
+    if rank == 0:
+        forget()
 
 
 def allgather_u32(values, max_local=None):

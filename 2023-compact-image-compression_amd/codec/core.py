@@ -204,7 +204,9 @@ class Decoder:
     def fulls(self):
         """core.py:508: raster indices of the pixels that arrived as full (two-byte) tokens, in stream order.  The
         reference collects them while parsing; here they are recomputed on demand from the decoded slice (the order
-        the pixels were written in is the encoder's partition of that same slice)."""
+        the pixels were written in is the encoder's partition of that same slice).  Equal to what the reference's
+        parser records for every stream an encoder can emit; for a hand-made stream (reserved tag bytes, a full token
+        where a short one would do) it is what an encoder WOULD have written for the decoded pixels, not what was parsed."""
         if self._fulls is None:
             if self._pixels is None:
                 return []

@@ -139,7 +139,9 @@ struct Context {
 	int device = -1;
 	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
 	int use_graph = 1;
-	int enc_slots = N_ENC_SLOTS;  // option "encode_slots": 1 = one encode batch on the device at a time
+	int enc_slots = 1;  // option "encode_slots": encode batches on the device at a time.  Default 1: on two of the three boxes
+	                    // measured a second batch in flight cost more (each kernel slows down next to another batch's
+	                    // DEFLATE pass) than it filled (bench.py reports both settings: stages.other_encode_slot_setting)
 	hipStream_t stream_dec = nullptr;  // decode runs on its own stream so it can overlap an encode in flight
 	std::map<std::pair<int, int>, ShapeTables> luts;  // (width,height) -> device tables
 	int use_tiles = 1;  // option "tile_path": 1 default choice among the tile paths (the streaming kernel wherever it applies), 4 the
@@ -943,7 +945,16 @@ int cct_device_info(char *name, size_t name_cap, int *compute_units, uint64_t *h
 	if (rc) return rc;
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, g_ctx.device));
-	if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+	if (name && name_cap) {
+		// the runtime of this image leaves hipDeviceProp_t::name empty for the MI355X: ask hipDeviceGetName, then fall back
+		char dn[256] = "";
+		if (prop.name[0]) snprintf(dn, sizeof dn, "%s", prop.name);
+		else if (hipDeviceGetName(dn, (int)sizeof dn, g_ctx.device) != hipSuccess || !dn[0]) {
+			(void)hipGetLastError();
+			snprintf(dn, sizeof dn, "gfx950 device, %d CUs", prop.multiProcessorCount);
+		}
+		snprintf(name, name_cap, "%s (%s)", dn, prop.gcnArchName);
+	}
 	if (compute_units) *compute_units = prop.multiProcessorCount;
 	if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
 	return CCT_OK;

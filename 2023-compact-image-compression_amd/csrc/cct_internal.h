@@ -101,7 +101,7 @@ struct StreamArgs {
 	                             //   [0] as ptab[0], [1] raster offset inside the tile of the pair's 8x4-pixel region
 	const uint32_t *otab, *ttab; // as PipeArgs (ttab entry: selectors, token bytes, kept bits of the low bytes)
 	int n_tiles, row_pitch, gps, tpg; // gps: groups per slice, tpg: tiles per group
-	int dbg;                     // tuning runs only (CCT_STREAM_DBG): 1 no carry wait, 2 no look-back (results then invalid)
+	int dbg;                     // tuning runs only (CCT_STREAM_DBG): 1 no carry wait, 2 no look-back (results then invalid), 4 wrong group guess (results valid)
 	uint64_t *hand;              // n * gps * 4 hand-off words, then
 	uint32_t *ticket;            // n group tickets (one allocation: zeroed by one memset before every launch)
 	uint64_t *spill_mask;        // n * NB: candidate masks beyond the LDS list of a tile

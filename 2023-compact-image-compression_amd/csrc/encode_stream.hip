@@ -216,14 +216,14 @@ struct Hand {  // the three words a group publishes (8-byte agent-scope stores; 
 constexpr uint64_t H_VALID = 1ull << 63;
 __device__ __forceinline__ void hand_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t hand_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-constexpr uint32_t SPIN_LIMIT = 1u << 22;   // polls (about a microsecond each) before a wait gives up with CCT_ST_INTERNAL
+constexpr uint32_t SPIN_LIMIT = 1u << 18;   // polls (a microsecond or more each) before a wait gives up with CCT_ST_INTERNAL
 
 // diagnostic build only (CCT_STREAM_STAMPS=1): shader clock at every phase boundary, per wave, to a buffer of their own
 #define STAMP(k) do { if (STAMPS) { __builtin_amdgcn_sched_barrier(0); st_[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 constexpr int N_STAMPS = 16;
 
 template <int SW, bool SGN, bool STAMPS>
-__global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t *stamps)
+__global__ void __launch_bounds__(64 * SW, 4) stream_kernel(StreamArgs a, uint64_t *stamps)
 {
 	using G = Geo<SW>;
 	constexpr int ST = G::ST, NBG = G::NBG, PAIR_FAST = G::PAIR_FAST;
@@ -255,51 +255,87 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	const bool seg = (a.e.flags & CCT_FLAG_SEGMENTATION) != 0;
 	const uint16_t *img = a.e.images + (size_t)sl * N;
 
-	// ---- tables, cleared state, ticket
-	if (tid < 64) otab[tid] = a.otab[tid];
-	else if (tid < 128) ((LDS(uint32_t) *)ttab)[tid - 64] = a.ttab[tid - 64];
-	for (int i = tid; i < (16 + NBG + HALO) / 4; i += ST) ((LDS(uint32_t) *)(lds + L_ROLE))[i] = 0u;
-	if (tid >= 1 && tid < 32) misc[tid] = 0u;
-	if (tid == 0) misc[M_TICKET] = atomicAdd(a.ticket + sl, 1u);
-	__syncthreads();
-	STAMP(1);
-	const int g = (int)misc[M_TICKET];
-	const int t0 = g * SW;
-	const int ntg = min(SW, NT - t0);                 // tiles of this group
-	const int nbg = ntg * 256;                        // its blocks
-	const int abs0 = t0 * 256;                        // slice index of its first block
-	const bool has_next = t0 + ntg < NT;              // a look-ahead exists
-	const bool active = wave < ntg;
-	Hand *hand = reinterpret_cast<Hand *>(a.hand) + (size_t)sl * gps;
-	// the predecessor's carry and last pixel: asked for now, looked at after the resolve (most groups have published both
-	// long before); lanes 0 and 1 of wave 0
-	uint64_t carry_v = 0;
-	if (wave == 0 && g > 0 && lane < 2 && !(a.dbg & 1)) carry_v = hand_load(lane == 0 ? &hand[g - 1].carry : &hand[g - 1].lastpx);
-
-	// ---- HBM -> VGPR -> LDS (traversal order)
-	{
-		uint32_t orall = 0;
-		if (active) {
-			const int t = t0 + wave;
+	// ---- ticket, tables, cleared state.  The pixel loads do not wait for the ticket: they are issued for the group the
+	// dispatch order suggests and repeated in the (never observed) case that the ticket says otherwise.
+	uint32_t tick = 0;
+	if (tid == 0) tick = atomicAdd(a.ticket + sl, 1u);
+	struct Loaded { u32x4 r[2][4]; uint32_t e[2]; u32x4 hr[4]; uint2 he; uint32_t before; };
+	auto issue_loads = [&](int gg, Loaded &L) {
+		const int t0_ = gg * SW, ntg_ = min(SW, NT - t0_);
+		if (wave == SW - 1) {
+			// the look-ahead: the first 64 traversal blocks of the next tile (32 block pairs, htab lists them; its entry is asked
+			// for first: the rows behind it wait for it only), and the pixel before the group
+			L.he = make_uint2(0u, 0u);
+			if (t0_ + ntg_ < NT) L.he = reinterpret_cast<const uint2 *>(a.htab)[TILE_ORIENT(a, t0_ + ntg_) * 32 + (lane & 31)];
+			L.before = 0;
+			if (t0_ > 0) L.before = img[TILE_ORG(a, t0_ - 1) + a.tiles.last[TILE_ORIENT(a, t0_ - 1)]];
+		}
+		if (wave < ntg_) {
+			const int t = t0_ + wave;
 			const uint32_t org = TILE_ORG(a, t);
 			const int to = TILE_ORIENT(a, t);
-			u32x4 r[2][4];
-			uint32_t e[2];
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
 				const int rl = 64 * h + lane;
 				const uint16_t *p = img + org + (size_t)((rl >> 3) * 4) * pitch + (rl & 7) * 8;
 #pragma unroll
-				for (int q = 0; q < 4; q++) r[h][q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
-				e[h] = a.ptab[(size_t)(to * 128 + rl) * 4];
+				for (int q = 0; q < 4; q++) L.r[h][q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
+				L.e[h] = a.ptab[(size_t)(to * 128 + rl) * 4];
 			}
+		}
+		if (wave == SW - 1 && t0_ + ntg_ < NT) {
+			const uint16_t *p = img + TILE_ORG(a, t0_ + ntg_) + L.he.y;
+#pragma unroll
+			for (int q = 0; q < 4; q++) L.hr[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
+		}
+	};
+	const int g_guess = (int)((blockIdx.x / (gridDim.x / gps) + ((a.dbg & 4) ? 1u : 0u)) % (uint32_t)gps);   // (dbg 4: a wrong guess on purpose)
+	// the tables are requested before the pixels (the loads of a wave return in order: what is needed first goes first)
+	const uint32_t tabv = tid < 64 ? a.otab[tid] : a.ttab[(tid - 64) & 63];
+	if (tid < 64) otab[tid] = tabv;
+	else if (tid < 128) ((LDS(uint32_t) *)ttab)[tid - 64] = tabv;
+	for (int i = tid; i < (16 + NBG + HALO) / 4; i += ST) ((LDS(uint32_t) *)(lds + L_ROLE))[i] = 0u;
+	if (tid < 32) misc[tid] = 0u;
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the pixel loads stay in flight
+	STAMP(1);
+	// Everything up to the first word handed to another group runs on the guess; the ticket is looked at there (it has
+	// arrived long before) and, should it differ, the group it names is processed instead.
+	Hand *hand = reinterpret_cast<Hand *>(a.hand) + (size_t)sl * gps;
+	int g = g_guess, t0, ntg, nbg, abs0;
+	bool has_next, active, wide, big, carry_lane;
+	uint64_t carry_v;
+	const uint64_t *carry_src;
+	uint32_t x[4][8], info[4];
+	uint64_t bal[4];
+	auto front = [&]() {  // pixels of group g -> LDS, analysis of the lane's blocks, ballots and ticket shared
+	Loaded L;
+	issue_loads(g, L);
+	t0 = g * SW;
+	ntg = min(SW, NT - t0);                 // tiles of this group
+	nbg = ntg * 256;                        // its blocks
+	abs0 = t0 * 256;                        // slice index of its first block
+	has_next = t0 + ntg < NT;               // a look-ahead exists
+	active = wave < ntg;
+	// the predecessor's carry and last pixel: asked for now, looked at after the resolve (most groups have published both
+	// long before); lanes 0 and 1 of wave 0
+	carry_v = 0;
+	carry_lane = wave == 0 && g > 0 && lane < 2 && !(a.dbg & 1);
+	carry_src = lane == 0 ? &hand[g > 0 ? g - 1 : 0].carry : &hand[g > 0 ? g - 1 : 0].lastpx;
+	if (carry_lane) carry_v = hand_load(carry_src);
+
+	// ---- VGPR -> LDS (traversal order)
+	{
+		uint32_t orall = 0;
+		if (active) {
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
+				const u32x4 *r = L.r[h];
+				const uint32_t e = L.e[h];
 				uint32_t dA[8], dB[8];
-				permute_block(r[h][0].x, r[h][0].y, r[h][1].x, r[h][1].y, r[h][2].x, r[h][2].y, r[h][3].x, r[h][3].y, otab + ((e[h] >> 8) & 3u) * 16, dA);
-				permute_block(r[h][0].z, r[h][0].w, r[h][1].z, r[h][1].w, r[h][2].z, r[h][2].w, r[h][3].z, r[h][3].w, otab + ((e[h] >> 24) & 3u) * 16, dB);
-				LDS(u32x4) *pa = (LDS(u32x4) *)(pix0 + 32 * (256 * wave + (int)(e[h] & 0xFFu)));
-				LDS(u32x4) *pb = (LDS(u32x4) *)(pix0 + 32 * (256 * wave + (int)((e[h] >> 16) & 0xFFu)));
+				permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((e >> 8) & 3u) * 16, dA);
+				permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((e >> 24) & 3u) * 16, dB);
+				LDS(u32x4) *pa = (LDS(u32x4) *)(pix0 + 32 * (256 * wave + (int)(e & 0xFFu)));
+				LDS(u32x4) *pb = (LDS(u32x4) *)(pix0 + 32 * (256 * wave + (int)((e >> 16) & 0xFFu)));
 				pa[0] = (u32x4){dA[0], dA[1], dA[2], dA[3]}; pa[1] = (u32x4){dA[4], dA[5], dA[6], dA[7]};
 				pb[0] = (u32x4){dB[0], dB[1], dB[2], dB[3]}; pb[1] = (u32x4){dB[4], dB[5], dB[6], dB[7]};
 #pragma unroll
@@ -307,33 +343,22 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 			}
 		}
 		if (wave == SW - 1) {
-			// the look-ahead: the first 64 traversal blocks of the next tile (32 block pairs, htab lists them), and the pixel
-			// before the group
 			if (has_next) {
-				const int t = t0 + ntg;
-				const uint32_t org = TILE_ORG(a, t);
-				const int to = TILE_ORIENT(a, t);
-				const uint2 he = reinterpret_cast<const uint2 *>(a.htab)[to * 32 + (lane & 31)];
-				const uint16_t *p = img + org + he.y;
-				u32x4 r[4];
-#pragma unroll
-				for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
+				const u32x4 *r = L.hr;
 				uint32_t dA[8], dB[8];
-				permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((he.x >> 8) & 3u) * 16, dA);
-				permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((he.x >> 24) & 3u) * 16, dB);
+				permute_block(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, otab + ((L.he.x >> 8) & 3u) * 16, dA);
+				permute_block(r[0].z, r[0].w, r[1].z, r[1].w, r[2].z, r[2].w, r[3].z, r[3].w, otab + ((L.he.x >> 24) & 3u) * 16, dB);
 				if (lane < 32) {
-					LDS(u32x4) *pa = (LDS(u32x4) *)(pix0 + 32 * (nbg + (int)(he.x & 0xFFu)));
-					LDS(u32x4) *pb = (LDS(u32x4) *)(pix0 + 32 * (nbg + (int)((he.x >> 16) & 0xFFu)));
+					LDS(u32x4) *pa = (LDS(u32x4) *)(pix0 + 32 * (nbg + (int)(L.he.x & 0xFFu)));
+					LDS(u32x4) *pb = (LDS(u32x4) *)(pix0 + 32 * (nbg + (int)((L.he.x >> 16) & 0xFFu)));
 					pa[0] = (u32x4){dA[0], dA[1], dA[2], dA[3]}; pa[1] = (u32x4){dA[4], dA[5], dA[6], dA[7]};
 					pb[0] = (u32x4){dB[0], dB[1], dB[2], dB[3]}; pb[1] = (u32x4){dB[4], dB[5], dB[6], dB[7]};
 				}
 #pragma unroll
 				for (int j = 0; j < 8; j++) orall |= dA[j] | dB[j];
 			}
-			uint32_t before = 0;
-			if (t0 > 0) before = img[TILE_ORG(a, t0 - 1) + a.tiles.last[TILE_ORIENT(a, t0 - 1)]];
-			if (lane == 0) *(LDS(uint32_t) *)(pix0 - 4) = before << 16;
-			orall |= before;
+			if (lane == 0) *(LDS(uint32_t) *)(pix0 - 4) = L.before << 16;
+			orall |= L.before;
 		}
 		const uint32_t wd = (__any((orall & 0xC000C000u) != 0) ? WIDE_14 : 0u) | (__any((orall & 0xF800F800u) != 0) ? WIDE_11 : 0u);
 		if (wd && lane == 0) lds_or(&misc[M_WIDE], wd);
@@ -342,14 +367,12 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	__syncthreads();
 	STAMP(3);
 	const uint32_t gw = misc[M_WIDE];
-	const bool wide = SGN || (gw & WIDE_14) != 0;     // exact (unpacked) arithmetic for the whole group
-	const bool big = (gw & WIDE_11) != 0;             // a delta outside [-2047, 2048] needs a pixel >= 2048
+	wide = SGN || (gw & WIDE_14) != 0;     // exact (unpacked) arithmetic for the whole group
+	big = (gw & WIDE_11) != 0;             // a delta outside [-2047, 2048] needs a pixel >= 2048
 
 	// ---- analysis of the lane's four blocks
 	// info[s]: two-byte bits (16) | tokens with two bytes << 16 (5) | transitions incl. the entering one << 21 (5) |
 	//          difficult << 26 | a delta out of the format's range among pixels 1..15 << 27 | the same for pixel 0 << 28
-	uint32_t x[4][8], info[4];
-	uint64_t bal[4];
 #pragma unroll
 	for (int s = 0; s < 4; s++) {
 		const int b = 256 * wave + 64 * s + lane;
@@ -401,6 +424,24 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		bal[s] = __ballot(difficult);
 	}
 
+	// the ballots of the difficult blocks are shared (the mask phase splits them among the waves), and with them the ticket
+	if (lane == 0) {
+#pragma unroll
+		for (int s = 0; s < 4; s++) dbal[wave * 4 + s] = bal[s];
+	}
+	if (tid == 0) misc[M_TICKET] = tick;
+	__syncthreads();
+	};
+	front();
+	if ((int)misc[M_TICKET] != g) {
+		// (never observed) the dispatch order and the ticket disagree: start over as the group the ticket names
+		g = (int)misc[M_TICKET];
+		__syncthreads();
+		if (tid < 32) misc[tid] = 0u;
+		__syncthreads();
+		front();
+	}
+	if (carry_lane && !(carry_v & H_VALID)) carry_v = hand_load(carry_src);   // asked again: the answer arrives during the mask phase
 	// No difficult block among the group's last 64 blocks: none of them can lead a pair, so nothing of the next group is
 	// taken and the group ends with its last block emitted alone -- the next group can be told right away
 	const bool last_group = g == gps - 1;
@@ -417,53 +458,56 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	// wave v of the ntg active ones takes the v-th quarter of the group's difficult blocks, in order (a tile full of bone
 	// would otherwise keep the other three waiting), so the per-wave lists concatenate to the ordered list the resolve walks.
 	// Entries with an empty mask are dropped: such a block can neither take a partner nor change the state of the walk.
-	if (lane == 0) {
-#pragma unroll
-		for (int s = 0; s < 4; s++) dbal[wave * 4 + s] = bal[s];
-	}
-	__syncthreads();
 	uint32_t cnt = 0;
 	if (active && seg) {
 		LDS(uint16_t) *my_idx = lidx + wave * LCAP;
 		LDS(uint64_t) *my_mask = lmask + wave * LCAP;
 		uint16_t *sp_idx = a.spill_idx + (size_t)sl * NB + abs0 + 256 * wave;
 		uint64_t *sp_mask = a.spill_mask + (size_t)sl * NB + abs0 + 256 * wave;
-		uint32_t D = 0;
-		for (int q = 0; q < 4 * ntg; q++) D += (uint32_t)__popcll(dbal[q]);
-		D = (uint32_t)__builtin_amdgcn_readfirstlane((int)D);
+		// lane q < 4 ntg holds the ballot of slot q; ordinals by a wave scan
+		const uint64_t myb = lane < 4 * ntg ? dbal[lane] : 0ull;
+		const uint32_t myc = (uint32_t)__popcll(myb);
+		const uint32_t inc = wave_incl_scan(myc);
+		const uint32_t D = rdlane(inc, 63);
 		const uint32_t lo = (uint32_t)wave * D / (uint32_t)ntg, hi = (uint32_t)(wave + 1) * D / (uint32_t)ntg;
-		// seek ordinal lo
+		const uint64_t nonempty = __ballot(myc != 0);
+		const uint32_t mlo = (uint32_t)myb, mhi = (uint32_t)(myb >> 32);
+		auto slot_mask = [&](int q) -> uint64_t { return (uint64_t)rdlane(mlo, q) | (uint64_t)rdlane(mhi, q) << 32; };
 		int sq = 0;
 		uint64_t bm = 0;
-		if (hi > lo) {
-			uint32_t skip = lo;
-			for (;;) {
-				const uint64_t v = dbal[sq];
-				bm = uniform64(v);
-				const uint32_t c = (uint32_t)__popcll(bm);
-				if (skip < c) break;
-				skip -= c; sq++;
-			}
-			for (; skip; skip--) bm &= bm - 1;
+		if (hi > lo) {   // seek ordinal lo: the first slot whose inclusive count exceeds it
+			sq = __builtin_ctzll(__ballot(inc > lo));
+			bm = slot_mask(sq);
+			for (uint32_t skip = lo - (rdlane(inc, sq) - rdlane(myc, sq)); skip; skip--) bm &= bm - 1;
 		}
-		for (uint32_t todo = hi - lo; todo; todo--) {
-			while (bm == 0) {
-				sq++;
-				const uint64_t v = dbal[sq];
-				bm = uniform64(v);
+		auto next_block = [&]() -> int {  // the next difficult block of the wave's range, group index (wave-uniform)
+			if (bm == 0) {
+				sq = __builtin_ctzll(nonempty & ~((2ull << sq) - 1ull));
+				bm = slot_mask(sq);
 			}
 			const int la = __builtin_ctzll(bm);
 			bm &= bm - 1;
-			const int ba = 64 * sq + la;                                          // block A, group index (wave-uniform)
-			const bool a_first = abs0 + ba == 0;
-			const LDS(uint8_t) *pA = pix0 + 32 * ba;
-			// every lane holds block A (one address: a broadcast read) and its own candidate B = A + lane
-			const u32x4 a0 = ((const LDS(u32x4) *)pA)[0], a1 = ((const LDS(u32x4) *)pA)[1];
+			return 64 * sq + la;
+		};
+		struct Cand { u32x4 a0, a1, w0, w1; uint32_t pt, pp; };
+		auto request = [&](int ba, Cand &c) {  // every lane: block A (one address: a broadcast read), its candidate B = A + lane,
+			const LDS(uint8_t) *pA = pix0 + 32 * ba;  // and pixel t = lane & 15 of A with its predecessor
+			c.a0 = ((const LDS(u32x4) *)pA)[0]; c.a1 = ((const LDS(u32x4) *)pA)[1];
 			const LDS(u32x4) *pq = (const LDS(u32x4) *)(pA + 32 * lane);
-			const u32x4 w0 = pq[0], w1 = pq[1];
+			c.w0 = pq[0]; c.w1 = pq[1];
+			c.pt = *(const LDS(uint16_t) *)(pA + 2 * (lane & 15)); c.pp = *(const LDS(uint16_t) *)(pA + 2 * (lane & 15) - 2);
+		};
+		Cand cn;
+		int ba_next = 0;
+		if (hi > lo) { ba_next = next_block(); request(ba_next, cn); }
+		for (uint32_t todo = hi - lo; todo; todo--) {
+			const int ba = ba_next;
+			const Cand c = cn;
+			if (todo > 1) { ba_next = next_block(); request(ba_next, cn); }   // in flight while this block is evaluated
+			const bool a_first = abs0 + ba == 0;
+			const u32x4 a0 = c.a0, a1 = c.a1, w0 = c.w0, w1 = c.w1;
 			// transitions of A including the entering one (cluster.py:110): lane t looks at pixel t
-			const int tcl = lane & 15;
-			int pt = (int)*(const LDS(uint16_t) *)(pA + 2 * tcl), pp_ = (int)*(const LDS(uint16_t) *)(pA + 2 * tcl - 2);
+			int pt = (int)c.pt, pp_ = (int)c.pp;
 			if (SGN) { pt = (int)(int16_t)pt; pp_ = (int)(int16_t)pp_; }
 			const uint32_t cur = (uint32_t)__popcll(__ballot(lane < 16 && !(a_first && lane == 0) && seg_large(pt - pp_)));
 			const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -507,6 +551,7 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		}
 	}
 	if (lane == 0) misc[M_CNT + wave] = cnt;
+	if (carry_lane && !(carry_v & H_VALID)) carry_v = hand_load(carry_src);
 	STAMP(5);
 	__syncthreads();
 	STAMP(6);
@@ -554,7 +599,6 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 					roles[i] = (uint8_t)j;
 					roles[i + j] = ROLE_PARTNER;
 					cw |= 1ull << j;
-					pairs[lds_add(&misc[M_NPAIRS], 1u)] = (uint16_t)i;
 				}
 			}
 			if (!more || inext - i > 63u) break;
@@ -610,7 +654,7 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		uint64_t v = carry_v;
 		uint32_t spins = 0;
 		bool ok = lane >= 2 || (v & H_VALID) != 0;
-		const uint64_t *src = lane == 0 ? &hand[g - 1].carry : &hand[g - 1].lastpx;
+		const uint64_t *src = carry_src;
 		while (!__all(ok)) {
 			if (!ok) { v = hand_load(src); ok = (v & H_VALID) != 0; }
 			if (++spins > SPIN_LIMIT) { if (lane == 0) lds_or(&misc[M_STATUS], CCT_ST_INTERNAL); break; }
@@ -632,6 +676,16 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 	STAMP(9);
 	if (wave == SW - 1 && !last_group && !carry_out_done && head_deferred && chain) publish_carry();
 	const uint32_t lastpx_in = misc[M_LASTPX];            // 0 for the first group: the slice starts from pixel value 0
+	// the meshed pairs, listed by their leaders' lanes
+	if (active) {
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			const int b = 256 * wave + 64 * s + lane;
+			const uint32_t r = roles[b];
+			if (r >= 1u && r < 0x80u) pairs[lds_add(&misc[M_NPAIRS], 1u)] = (uint16_t)b;
+		}
+	}
+	__syncthreads();
 
 	// last pixel written before block b's group in the final order (b alone or a leader)
 	auto prev_px_final = [&](int b) -> uint32_t {
@@ -747,14 +801,54 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		const uint32_t r = active ? roles[b] : 0u;
 		if (r >= 1u && r < 0x80u) boff[b] = (uint16_t)off[s];    // the pair's lane finds its offset here
 	}
+	// hand on the totals and ask for the predecessors' (one lane each); the answers are looked at after the image is built
+	uint64_t lb_v = 0;
 	if (wave == 0) {
-		// hand on the totals, then collect the predecessors' (at most 63 of them: one lane each)
 		if (lane == 0) hand_store(&hand[g].total, H_VALID | (uint64_t)gtot | (uint64_t)npairs << 24 | (uint64_t)misc[M_NDIFF] << 40);
+		if (lane < g && !(a.dbg & 2)) lb_v = hand_load(&hand[lane].total);
+	}
+	STAMP(12);
+
+	// ---- the pixel stage becomes the payload image (from its byte 0: where the group starts in the slice is not known yet)
+	LDS(uint8_t) *stg = lds + L_PIX;
+	const bool eofb = last_group && a.e.eof >= 0;
+	const uint32_t tot = gtot + (eofb ? 1u : 0u);
+	{
+		const uint32_t zc = min((uint32_t)(L_IMG_BYTES / 16), (tot + 15u) / 16u + 3u);
+		for (uint32_t c = tid; c < zc; c += ST) *(LDS(u32x4) *)(stg + c * 16) = (u32x4){0, 0, 0, 0};
+	}
+	__syncthreads();
+	STAMP(13);
+	if (wave == 0 && lane < g && !(lb_v & H_VALID) && !(a.dbg & 2)) lb_v = hand_load(&hand[lane].total);   // asked again
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		const int b = 256 * wave + 64 * s + lane;
+		const uint32_t r = active ? roles[b] : 0xFFu;
+		if (r == 0) (void)emit16(x[s], info[s] & 0xFFFFu, off[s], stg, ttab);
+	}
+	if ((uint32_t)tid < npairs) {
+		uint32_t o = boff[p_i];
+		lds_or((LDS(uint32_t) *)(stg + (o & ~3u)), (0x80u | p_j) << ((o & 3u) * 8u));   // core.py:290-294
+		o = emit16(px_, p_mb & 0xFFFFu, o + 1u, stg, ttab);
+		(void)emit16(px_ + 8, p_mb >> 16, o, stg, ttab);
+	}
+	if (npairs > (uint32_t)PAIR_FAST) {
+		const uint8_t *rec0 = a.pairrec + ((size_t)sl * (NB / 2) + (size_t)g * (NBG / 2)) * PIPE_PAIR_REC;
+		for (uint32_t e = PAIR_FAST + tid; e < npairs; e += ST) {
+			const int i = pairs[e], p = i + roles[i];
+			const uint32_t n = 33u + (roles[p] & 0x7Fu), o = boff[i];
+			const uint8_t *src = rec0 + (size_t)(e - PAIR_FAST) * PIPE_PAIR_REC;
+			for (uint32_t j = 0; j < n; j++) stg[o + j] = src[j];
+		}
+	}
+	if (eofb && tid == 0) stg[gtot] = (uint8_t)a.e.eof;   // core.py:329-330 (nothing else writes this byte)
+	if (wave == 0) {
+		// the bytes before the group: the predecessors' totals, 64 at a time
 		uint32_t bytes = 0, nj = 0, ndf = 0, spins = 0;
 		if (a.dbg & 2) bytes = (uint32_t)g * (uint32_t)(NBG * 20);
-		else for (int c0 = 0; c0 < g; c0 += 64) {   // 64 predecessors at a time, one lane each
-			uint64_t v = 0;
-			bool ok = c0 + lane >= g;
+		else for (int c0 = 0; c0 < g; c0 += 64) {
+			uint64_t v = c0 == 0 ? lb_v : 0ull;
+			bool ok = c0 + lane >= g || (v & H_VALID) != 0;
 			while (!__all(ok)) {
 				if (!ok) { v = hand_load(&hand[c0 + lane].total); ok = (v & H_VALID) != 0; }
 				if (++spins > SPIN_LIMIT) { if (lane == 0) lds_or(&misc[M_STATUS], CCT_ST_INTERNAL); break; }
@@ -767,61 +861,37 @@ __global__ void __launch_bounds__(64 * SW) stream_kernel(StreamArgs a, uint64_t 
 		}
 		if (lane == 0) { misc[M_BASE] = bytes; misc[M_ACC_JUMP] = nj; misc[M_ACC_DIFF] = ndf; }
 	}
-	STAMP(12);
-	__syncthreads();
-	STAMP(13);
-
-	// ---- the pixel stage becomes the payload image
-	const uint32_t base = misc[M_BASE];
-	const uint32_t head = base & 15u;
-	LDS(uint8_t) *stg = lds + L_PIX;
-	const bool eofb = last_group && a.e.eof >= 0;
-	const uint32_t end = head + gtot + (eofb ? 1u : 0u);
-	{
-		const uint32_t zc = min((uint32_t)(L_IMG_BYTES / 16), (end + 15u) / 16u + 1u);
-		for (uint32_t c = tid; c < zc; c += ST) *(LDS(u32x4) *)(stg + c * 16) = (u32x4){0, 0, 0, 0};
-	}
-	__syncthreads();
-#pragma unroll
-	for (int s = 0; s < 4; s++) {
-		const int b = 256 * wave + 64 * s + lane;
-		const uint32_t r = active ? roles[b] : 0xFFu;
-		if (r == 0) (void)emit16(x[s], info[s] & 0xFFFFu, head + off[s], stg, ttab);
-	}
-	if ((uint32_t)tid < npairs) {
-		uint32_t o = head + boff[p_i];
-		lds_or((LDS(uint32_t) *)(stg + (o & ~3u)), (0x80u | p_j) << ((o & 3u) * 8u));   // core.py:290-294
-		o = emit16(px_, p_mb & 0xFFFFu, o + 1u, stg, ttab);
-		(void)emit16(px_ + 8, p_mb >> 16, o, stg, ttab);
-	}
-	if (npairs > (uint32_t)PAIR_FAST) {
-		const uint8_t *rec0 = a.pairrec + ((size_t)sl * (NB / 2) + (size_t)g * (NBG / 2)) * PIPE_PAIR_REC;
-		for (uint32_t e = PAIR_FAST + tid; e < npairs; e += ST) {
-			const int i = pairs[e], p = i + roles[i];
-			const uint32_t n = 33u + (roles[p] & 0x7Fu), o = head + boff[i];
-			const uint8_t *src = rec0 + (size_t)(e - PAIR_FAST) * PIPE_PAIR_REC;
-			for (uint32_t j = 0; j < n; j++) stg[o + j] = src[j];
-		}
-	}
-	if (eofb && tid == 0) stg[head + gtot] = (uint8_t)a.e.eof;   // core.py:329-330 (nothing else writes this byte)
 	__syncthreads();
 	STAMP(14);
 
-	// ---- flush: whole 16-byte chunks with one store, the two ends shared with the neighbouring groups byte by byte
+	// ---- flush.  Byte q of the image belongs at base + q of the slice's payload: 16-byte chunks of the payload are put
+	// together from five image dwords (v_perm by the byte phase) and stored whole; the two ends shared with the neighbouring
+	// groups go byte by byte.
 	uint32_t stat = misc[M_STATUS];
+	const uint32_t base = misc[M_BASE];
 	{
+		const uint32_t head = base & 15u;
+		const uint32_t end = head + tot;                                      // in bytes from the chunk the group starts in
 		const size_t base16 = (size_t)(base & ~15u);
 		const bool room = base16 + ((end + 15u) & ~15u) <= a.e.stride;
 		uint8_t *out = a.e.payload + (size_t)sl * a.e.stride + base16;
 		const uint32_t c_first = head ? 1u : 0u;
 		const uint32_t c_end = last_group ? (end + 15u) / 16u : end / 16u;   // the last group owns the padding of the slice
 		if (room) {
-			for (uint32_t c = c_first + tid; c < c_end; c += ST)
-				*reinterpret_cast<u32x4 *>(out + (size_t)c * 16) = *(const LDS(u32x4) *)(stg + c * 16);
-			if (head && tid < 16 && (uint32_t)tid >= head && (uint32_t)tid < end) out[tid] = stg[tid];
+			if (head == 0) {
+				for (uint32_t c = tid; c < c_end; c += ST) *reinterpret_cast<u32x4 *>(out + (size_t)c * 16) = *(const LDS(u32x4) *)(stg + c * 16);
+			} else {
+				const uint32_t sel = 0x03020100u + 0x01010101u * ((0u - head) & 3u);
+				for (uint32_t c = c_first + tid; c < c_end; c += ST) {
+					const LDS(uint32_t) *w = (const LDS(uint32_t) *)(stg + ((16u * c - head) & ~3u));
+					const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+					*reinterpret_cast<u32x4 *>(out + (size_t)c * 16) = (u32x4){perm(d1, d0, sel), perm(d2, d1, sel), perm(d3, d2, sel), perm(d4, d3, sel)};
+				}
+				if (tid < 16 && (uint32_t)tid >= head && (uint32_t)tid < end) out[tid] = stg[(uint32_t)tid - head];
+			}
 			if (!last_group && tid >= 16 && tid < 32) {
 				const uint32_t i = c_end * 16u + (uint32_t)(tid - 16);
-				if (i < end && (i >= 16u || !head)) out[i] = stg[i];
+				if (i < end && (i >= 16u || !head)) out[i] = stg[i - head];
 			}
 		} else stat |= CCT_ST_CAP;
 	}
@@ -859,7 +929,7 @@ static void report_stream_stamps(const uint64_t *d_buf, size_t nwaves)
 	std::vector<uint64_t> h(nwaves * W);
 	if (hipMemcpy(h.data(), d_buf, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
 	static const char *const name[N_STAMPS - 1] = {"tables+ticket", "loads+permute", "barrier 1", "analysis", "masks", "barrier 2", "resolve", "carry wait",
-	                                               "barrier 4", "pairs", "sizes", "totals+lookback", "barrier 7", "zero+emit", "flush"};
+	                                               "barrier 4", "pairs", "sizes", "totals", "zero", "emit+lookback", "flush"};
 	double sum[N_STAMPS] = {0};
 	std::vector<double> life, start, endt;
 	uint64_t t0 = ~0ull;

@@ -5,7 +5,9 @@
     (N > 1: launched by the driver as python -m torch.distributed.run ... bench.py --gpus N ...)
 
 Workloads (BASELINE.json `configs`):
-  --config 2 (default, the headline)  256 device-resident synthetic 12-bit 512x512 CT slices per GPU and step: encoded to
+  --config 2 (default, the headline)  256 device-resident synthetic 12-bit 512x512 CT slices per GPU and step (phantoms that
+             use the 12-bit container as the real corpus does, values up to ~2200; --phantom 11bit gives rounds 1-2's
+             phantoms, all below 2048): encoded to
              byte-exact .cct files (transform+pack kernels, device DEFLATE bit-identical to zlib level 9, one packed D2H
              into a page-locked archive) and decoded back to rasters in HBM (archive H2D, device INFLATE, token/scatter
              kernel).  Three distinct batches rotate so the working set (3 x 134 MB) exceeds the 256 MiB Infinity Cache.
@@ -16,7 +18,7 @@ only exchange is the all-gather of the per-slice compressed sizes over RCCL, rea
 (cct_comm_init / cct_allgather_u32; the communicator id travels from rank 0 through a file): no PyTorch in this script.
 
 One JSON line on stdout (rank 0): metric/value as the driver contract says, plus
-  roofline      the transform+pack stage (the four kernels of encode_pipe.hip; decode-only: INFLATE + decode kernel):
+  roofline      the transform+pack stage (stream_kernel of encode_stream.hip; decode-only: INFLATE + decode kernel):
                 algorithmic HBM bytes per launch / mean stage time from HIP events recorded on the library's own stream
                 around every launch of the timed region, against 8 TB/s; `traffic` from profiles/ only while the kernel
                 source still has the hash the counters were collected with;
@@ -44,8 +46,8 @@ for p in (ROOT, PKG):
 BS = 16
 N_ROT = 3
 HBM_PEAK_GBS = 8000.0
-PIPE_SRC = os.path.join(PKG, "csrc", "encode_pipe.hip")
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_encode.json")
+PIPE_SRC = os.path.join(PKG, "csrc", "encode_stream.hip")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_encode.json")
 WORKLOADS = {2: (512, 256), 4: (1024, 512), 5: (512, 256)}  # config -> (edge, slices per GPU and step)
 
 
@@ -74,18 +76,40 @@ def _cpu_model():
 
 
 def _phantom_job(args):
+    """ct_phantom(seed, edge, depth12), through a cache on local disk: the driver runs N = 1, 2, 4, 8 back to back and
+    rank r of a wider run needs the seeds a narrower one has already made."""
     from cct_hip.synth import ct_phantom
-    return ct_phantom(*args)
+    seed, edge, depth12 = args
+    cache = os.environ.get("CCT_PHANTOM_CACHE", os.path.join("/tmp", f"cct_phantoms_{os.getuid()}"))
+    path = os.path.join(cache, f"{edge}_{int(depth12)}_{seed}.npy") if cache != "0" else None
+    if path:
+        try:
+            a = np.load(path)
+            if a.shape == (edge, edge) and a.dtype == np.uint16:
+                return a
+        except (OSError, ValueError):
+            pass
+    a = ct_phantom(seed, edge, depth12)
+    if path:
+        try:
+            os.makedirs(cache, exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp.npy"
+            np.save(tmp, a)
+            os.replace(tmp, path)
+        except OSError:
+            pass
+    return a
 
 
-def make_batches(rank, n_slices, edge=512):
+def make_batches(rank, n_slices, edge=512, depth12=True):
     """Batch 0 = ct_phantom(seed) for distinct seeds (rank-disjoint; 1024x1024: 32 distinct phantoms, tiled, which keeps
     the generation time of 512 slices bounded); batches 1, 2 are its left-right / up-down mirrors: distinct bytes in
     HBM, same statistics.  Uses a process pool: call it BEFORE anything initialises the GPU (fork)."""
     from concurrent.futures import ProcessPoolExecutor
     distinct = n_slices if edge <= 512 else min(n_slices, 32)
-    seeds = [(rank * n_slices + i, edge) for i in range(distinct)]
-    workers = max(1, min(16, _usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    seeds = [(rank * n_slices + i, edge, depth12) for i in range(distinct)]
+    # at least four workers per rank also when eight ranks share the host (two each took 4-5 s before the first GPU call)
+    workers = max(min(4, _usable_cpus()), min(16, _usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     if workers > 1:
         with ProcessPoolExecutor(workers) as ex:
             imgs = list(ex.map(_phantom_job, seeds, chunksize=4))
@@ -155,6 +179,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--slices", type=int, default=None, help="slices per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phantom", default="12bit", choices=("12bit", "11bit"),
+                    help="synthetic slices: 12bit = cct_hip.synth.ct_phantom(depth12=True), bone at 1900-2150 and values above 2047 "
+                         "like the real corpus; 11bit = the phantoms of rounds 1-2 (every value below 2048)")
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
     ap.add_argument("--no-slot-comparison", action="store_true",
                     help="skip the short run with the other --encode-slots setting after the timed region (use under a tracer)")
@@ -177,7 +204,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     # ---- host-side work that forks: before any GPU / RCCL initialisation
-    batches = make_batches(rank, n, edge)
+    batches = make_batches(rank, n, edge, args.phantom == "12bit")
+    phantom_note = ("12-bit phantoms: bone at 1900-2150 + texture, values above 2047 as in the real corpus, Q7-safe by construction"
+                    if args.phantom == "12bit" else "11-bit phantoms of rounds 1-2: every value below 2048")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batches[0])
@@ -384,8 +413,8 @@ def main():
                 r.update(extra)
             return r
 
-        pack = roof("transform+pack stage: pipe_analyse_kernel + pipe_masks_kernel + pipe_resolve_kernel + pipe_pack_kernel "
-                    "(image -> token payload), events around the four launches", 2.0 * npx, enc_kernel_ms,
+        pack = roof("transform+pack stage: stream_kernel (image -> token payload, one pass), events around its launch",
+                    2.0 * npx, enc_kernel_ms,
                     {"traffic": traffic, "traffic_source": traffic_src,
                      "read_plus_write_GBs": round((2.0 * npx + payload_per_launch) / (enc_kernel_ms * 1e-3) / 1e9, 1),
                      "avg_kernel_ms": round(enc_kernel_ms, 4),
@@ -412,8 +441,9 @@ def main():
             "value": round(value, 2), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of {n} synthetic {W}x{H} uint16 CT slices per GPU, "
-                                   f"{what}, {N_ROT} rotating device-resident batches",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: batch of {n} synthetic {W}x{H} uint16 CT slices per GPU "
+                                   f"({phantom_note}), {what}, {N_ROT} rotating device-resident batches",
+                       "phantom": args.phantom, "max_pixel_value": int(max(int(b.max()) for b in batches)),
                        "slices_per_gpu": n, "width": W, "height": H, "block_size": bs,
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)",
                        "encode_slots": args.encode_slots},

@@ -13,9 +13,10 @@
  * CCT_E_* code and never throws; buffers are caller-allocated; "d_" pointers are device
  * (HBM) addresses obtained from cct_dev_alloc (or any hipMalloc), "h_" pointers are host
  * addresses.  Threading: calls may come from several host threads.  An encode batch call
- * (cct_encode_batch, cct_encode_batch_packed) takes one of two internal encode slots -- a
- * HIP stream with its own workspaces -- so two of them run side by side on the device and a
- * third waits (option "encode_slots" = 1: one at a time); decode calls (cct_decode_batch,
+ * (cct_encode_batch, cct_encode_batch_packed) takes an internal encode slot -- a HIP stream
+ * with its own workspaces; by default there is one, so a second call waits (option
+ * "encode_slots" = 2: two batches side by side on the device, which pays on some boxes only,
+ * see DESIGN.md); decode calls (cct_decode_batch,
  * cct_zlib_decompress_batch) likewise take one of two decode slots ("decode_slots"), next to
  * the encodes; the size gather (cct_allgather_u32) has its own stream as well.  Everything else
  * shares the main stream (= encode slot 0) under one mutex.  The streams are NOT ordered

@@ -106,7 +106,7 @@ def test_options_round_trip_without_a_device():
                              (b"tile_path", 9, 1), (b"device_inflate", 5, 1), (b"deflate_graph", 0, 0), (b"deflate_graph", 1, 1)):
         assert L.cct_set_option(key, given) == 0
         assert L.cct_get_option(key, C.byref(v)) == 0 and v.value == want, (key, given, v.value)
-    assert L.cct_set_option(b"encode_slots", 2) == 0 and L.cct_set_option(b"tile_path", 1) == 0
+    assert L.cct_set_option(b"encode_slots", 1) == 0 and L.cct_set_option(b"tile_path", 1) == 0
     assert L.cct_set_option(b"deflate_ways", 2) != 0      # removed in round 2
     assert L.cct_set_option(b"no_such_option", 1) != 0
     assert L.cct_get_option(b"no_such_option", C.byref(v)) != 0
@@ -138,7 +138,7 @@ def test_shutdown_twice_and_from_threads():
 
 def test_bench_traffic_figure_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
     """bench.py prints the PMC traffic of the transform+pack stage only while the SHA-1 stored with it is the SHA-1 of
-    encode_pipe.hip; and the summary committed under profiles/ belongs to the source committed next to it."""
+    encode_stream.hip; and the summary committed under profiles/ belongs to the source committed next to it."""
     import hashlib
     import json
     sys.path.insert(0, ROOT)
@@ -147,9 +147,9 @@ def test_bench_traffic_figure_is_tied_to_the_kernel_source(tmp_path, monkeypatch
         sha = hashlib.sha1(f.read()).hexdigest()
     with open(bench.PMC_JSON) as f:
         pmc = json.load(f)
-    assert pmc["source_sha1"] == sha, "encode_pipe.hip changed after the PMC passes: re-run tools/gpu_round_end.sh + collect_profiles.py"
+    assert pmc["source_sha1"] == sha, "encode_stream.hip changed after the PMC passes: re-run tools/gpu_round_end.sh + collect_profiles.py"
     traffic, src = bench.pmc_traffic()
-    assert traffic == pmc["traffic_bytes_per_launch"] and traffic > pmc["algorithmic_read_bytes"] and "r02_pmc_encode.json" in src
+    assert traffic == pmc["traffic_bytes_per_launch"] and traffic > pmc["algorithmic_read_bytes"] and "r03_pmc_encode.json" in src
     stale = tmp_path / "pmc.json"
     stale.write_text(json.dumps(dict(pmc, source_sha1="0" * 40)))
     monkeypatch.setattr(bench, "PMC_JSON", str(stale))

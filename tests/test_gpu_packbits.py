@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import packbits_oracle as po
-from test_packbits_oracle import KATS
+from test_packbits_oracle import KATS, golden_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,18 @@ def test_known_answers_and_mirror_class():
         assert list(PackBits(delta).decode(enc)) == data
     assert PackBits().encode([]) == []
     assert PackBits().encode([9]) == b"\x00\x09"
+
+
+def test_kernels_equal_the_reference_on_the_fixture():
+    """tests/golden/packbits.json: 301 strings encoded by the reference's own PackBits in both delta modes."""
+    from codec import packbits
+    cases = list(golden_cases())
+    blobs = [c[0] for c in cases]
+    for delta, col in ((False, 1), (True, 2)):
+        enc = packbits.encode_batch(blobs, delta)
+        assert [bytes(e) for e in enc] == [c[col] for c in cases]
+        dec = packbits.decode_batch([c[col] for c in cases], delta, max_out=4096)
+        assert [bytes(d) for d in dec] == blobs
 
 
 def test_batches_vs_oracle():

@@ -1,6 +1,29 @@
-"""CPU: the PackBits oracle against the known answers of the reference (the first one is what
-src/codec/packbits.py:166-177 prints)."""
+"""CPU: the PackBits oracle against the reference: tests/golden/packbits.json holds 301 strings with what the reference's
+own PackBits gives for them (oracle/gen_packbits_golden.py imports it in the build container), next to the known answers of
+SURVEY Appendix C (the first one is what src/codec/packbits.py:166-177 prints)."""
+import base64
+import json
+import os
+
 from oracle import packbits_oracle as po
+
+
+def golden_cases():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "packbits.json")) as f:
+        g = json.load(f)
+    for c in g["cases"]:
+        yield base64.b64decode(c["data"]), base64.b64decode(c["plain"]), base64.b64decode(c["delta"])
+
+
+def test_oracle_equals_the_reference_on_the_fixture():
+    n = 0
+    for data, plain, delta in golden_cases():
+        assert bytes(po.encode(list(data), False)) == plain
+        assert bytes(po.encode(list(data), True)) == delta
+        assert bytes(bytearray(po.decode(plain, False))) == data
+        assert bytes(bytearray(po.decode(delta, True))) == data
+        n += 1
+    assert n >= 300
 
 KATS = [
     ([3, 255, 3, 255, 3, 255, 3, 255, 20, 255], False, [9, 3, 255, 3, 255, 3, 255, 3, 255, 20, 255]),

@@ -11,9 +11,10 @@ PKG = os.path.join(ROOT, "2023-compact-image-compression_amd")
 
 WORKER = r"""
 import os, sys, numpy as np
-sys.path.insert(0, {pkg!r})
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {here!r})
 import torch.distributed as dist
-from cct_hip.parallel import shard_range, gather_sizes, file_offsets
+from cct_hip.parallel import shard_range, file_offsets
+from gloo_gather import gather_sizes
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n_total = 3954 if len(sys.argv) < 2 else int(sys.argv[1])
@@ -31,7 +32,7 @@ print("rank", rank, "ok", lo, hi)
 
 
 def _run(world, n_total):
-    code = WORKER.format(pkg=PKG)
+    code = WORKER.format(pkg=PKG, here=HERE)
     procs = []
     port = 29500 + (os.getpid() % 2000)
     for r in range(world):
@@ -87,6 +88,31 @@ def test_unique_id_file_rendezvous(tmp_path):
     for p in ps:
         p.join(30)
     assert got[0] == got[1] == bytes(range(128))
+
+
+def test_rendezvous_ignores_a_stale_id_and_keys_on_the_launch(tmp_path, monkeypatch):
+    """A 128-byte file left by a launch that died must not be read as this launch's id: ranks other than 0 skip files older
+    than their own process; rank 0 replaces the file.  The file name comes from what the launcher exports to every rank
+    (address, port, run id), the parent pid only when none of that exists."""
+    import time
+    from cct_hip import parallel
+    stale = tmp_path / "cct_rccl_id_unit2"
+    stale.write_bytes(b"\xee" * 128)
+    old = time.time() - 3600
+    os.utime(stale, (old, old))
+    with __import__("pytest").raises(TimeoutError):
+        parallel.exchange_unique_id(1, 2, None, directory=str(tmp_path), key="unit2", timeout_s=0.3)
+    blob, path = parallel.exchange_unique_id(0, 2, lambda: bytes(range(128)), directory=str(tmp_path), key="unit2")
+    assert blob == bytes(range(128)) and open(path, "rb").read() == blob
+    assert parallel.exchange_unique_id(1, 2, None, directory=str(tmp_path), key="unit2", timeout_s=5)[0] == blob
+    for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"):
+        monkeypatch.delenv(k, raising=False)
+    assert parallel.rendezvous_key() == f"ppid_{os.getppid()}"
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", "29511")
+    k1 = parallel.rendezvous_key()
+    assert "29511" in k1 and str(os.getppid()) not in k1.split("_")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
+    assert parallel.rendezvous_key() != k1 and "/" not in parallel.rendezvous_key()
 
 
 def test_allgather_without_communicator_is_a_copy():

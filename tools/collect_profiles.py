@@ -16,8 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "round_end")
 DST = os.path.join(ROOT, "profiles")
-PIPE_SRC = os.path.join(ROOT, "2023-compact-image-compression_amd", "csrc", "encode_pipe.hip")
-KERNELS = ("pipe_analyse_kernel", "pipe_masks_kernel", "pipe_resolve_kernel", "pipe_pack_kernel")
+PIPE_SRC = os.path.join(ROOT, "2023-compact-image-compression_amd", "csrc", "encode_stream.hip")
+KERNELS = ("stream_kernel",)
 
 
 def per_kernel(path, counter):
@@ -27,7 +27,7 @@ def per_kernel(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(pipe_\w+_kernel)", row["Kernel_Name"])
+            m = re.search(r"(stream_kernel)", row["Kernel_Name"])
             if not m:
                 continue
             tot[m.group(1)] += float(row["Counter_Value"])
@@ -36,11 +36,13 @@ def per_kernel(path, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     keep = ["bench.json", "bench_under_rocprof.json", "bench_kernel_stats.csv", "bench_two_slots.json",
             "bench_two_slots_under_rocprof.json", "bench_two_slots_kernel_stats.csv", "bench_no_overlap.json",
             "bench_config4.json", "bench_config5.json", "pmc_FETCH_SIZE_counter_collection.csv",
-            "pmc_WRITE_SIZE_counter_collection.csv", "pmc_sq_counter_collection.csv", "prof_encode.log", "prof_codec.log", "codec_serial_kernel_stats.csv"]
+            "pmc_WRITE_SIZE_counter_collection.csv", "pmc_sq_counter_collection.csv", "prof_encode.log", "prof_codec.log", "codec_serial_kernel_stats.csv",
+            "pmc_codec_FETCH_SIZE_counter_collection.csv", "pmc_codec_WRITE_SIZE_counter_collection.csv", "pmc_codec_sq_counter_collection.csv",
+            "pmc_codec.json", "stream_stamps.log"]
     for name in keep:
         p = os.path.join(SRC, name)
         if os.path.exists(p):
@@ -62,7 +64,7 @@ def main():
            "workload": "256 x 512x512 uint16 (bench batch), tools/prof_encode.py --paths 1",
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; counters are KB, summed over "
                      "the reported dimensions, averaged over the dispatches; x2 on the read side (gfx950, 16-byte-per-lane reads); "
-                     "one 'launch' = the four kernels of the stage",
+                     "one 'launch' = the one kernel of the stage (stream_kernel)",
            "algorithmic_read_bytes": 256 * 512 * 512 * 2}
     with open(os.path.join(DST, f"{tag}_pmc_encode.json"), "w") as f:
         json.dump(out, f, indent=1)
