@@ -291,9 +291,11 @@ __global__ void __launch_bounds__(64 * SW, 4) stream_kernel(StreamArgs a, uint64
 	};
 	const int g_guess = (int)((blockIdx.x / (gridDim.x / gps) + ((a.dbg & 4) ? 1u : 0u)) % (uint32_t)gps);   // (dbg 4: a wrong guess on purpose)
 	// the tables are requested before the pixels (the loads of a wave return in order: what is needed first goes first)
-	const uint32_t tabv = tid < 64 ? a.otab[tid] : a.ttab[(tid - 64) & 63];
-	if (tid < 64) otab[tid] = tabv;
-	else if (tid < 128) ((LDS(uint32_t) *)ttab)[tid - 64] = tabv;
+	for (int i = tid; i < 128; i += ST) {   // (a workgroup of one wave makes two rounds)
+		const uint32_t tabv = i < 64 ? a.otab[i] : a.ttab[i - 64];
+		if (i < 64) otab[i] = tabv;
+		else ((LDS(uint32_t) *)ttab)[i - 64] = tabv;
+	}
 	for (int i = tid; i < (16 + NBG + HALO) / 4; i += ST) ((LDS(uint32_t) *)(lds + L_ROLE))[i] = 0u;
 	if (tid < 32) misc[tid] = 0u;
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the pixel loads stay in flight

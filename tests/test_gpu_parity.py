@@ -427,11 +427,15 @@ def test_unsupported_block_sizes_are_refused(hip):
     """The reference accepts any divisor of W*H as block_size (core.py:245); the HIP path carries 4, 8, 16, 32 and 64 (what
     config.json ships and SURVEY App. C pins) and refuses the rest with CCT_E_ARG -> ValueError, before touching the device."""
     img = gi.ct_phantom(5, 128)
-    for bs in (2, 128, 1, 3, 256):
+    for bs in (2, 128, 1, 256, 512):
         cfg = hip.default_config()
         cfg["block_size"] = bs
         with pytest.raises(ValueError, match="block_size"):
             hip.encode_batch(img[None], cfg)
+    cfg = hip.default_config()
+    cfg["block_size"] = 3   # not a divisor: the reference's own error (numpy reshape, core.py:245)
+    with pytest.raises(ValueError, match="cannot reshape"):
+        hip.encode_batch(img[None], cfg)
 
 
 @pytest.mark.parametrize("n_px", [128, 256, 512, 1024])
@@ -485,8 +489,10 @@ def test_tile_path_equals_generic_path(hip, n_px):
     stride = payload_stride(w, h, 16)
     d_img = DeviceBuffer.from_numpy(imgs)
     res = []
-    for tile, ran in ((4, 3), (3, 1), (2, 2), (0, 0)):  # option value, implementation that must have run
+    # option value, implementation that must have run, tiles per workgroup of the streaming kernel (4 is the default)
+    for tile, ran, tpg in ((4, 3, 4), (4, 3, 2), (4, 3, 1), (3, 1, 4), (2, 2, 4), (0, 0, 4)):
         _ffi.check(L.cct_set_option(b"tile_path", tile))
+        _ffi.check(L.cct_set_option(b"stream_tpg", tpg))
         d_pay, d_sz, d_st = DeviceBuffer(n * stride), DeviceBuffer(4 * n), DeviceBuffer(4 * n)
         d_stats, d_roles = DeviceBuffer(16 * n), DeviceBuffer(n * nb)
         d_pay.zero()
@@ -497,6 +503,7 @@ def test_tile_path_equals_generic_path(hip, n_px):
                     d_roles.download(np.uint8, n * nb),
                     [d_pay.download(np.uint8, int(sizes[i]), offset=i * stride).tobytes() for i in range(n)]))
     _ffi.check(L.cct_set_option(b"tile_path", 1))
+    _ffi.check(L.cct_set_option(b"stream_tpg", 4))
     for other in res[1:]:
         for a_, b_ in zip(res[0][:4], other[:4]):
             assert np.array_equal(a_, b_)

@@ -69,6 +69,55 @@ def main():
     with open(os.path.join(DST, f"{tag}_pmc_encode.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
+    codec_summary(tag)
+
+
+def codec_summary(tag):
+    """Per kernel of the serial encode / decode calls (tools/prof_codec.py): FETCH_SIZE / WRITE_SIZE (KB, as counted: the x2
+    of the gfx950 note applies to 16-byte-per-lane streaming reads only and is NOT applied here) and the SQ counters,
+    averaged over the dispatches."""
+    def table(name, counters):
+        path = os.path.join(SRC, name)
+        if not os.path.exists(path):
+            return {}
+        acc, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] not in counters:
+                    continue
+                m = re.search(r"(\w+_kernel)", row["Kernel_Name"])
+                k = m.group(1) if m else row["Kernel_Name"][:48]
+                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                disp[k].add(row["Dispatch_Id"])
+        return {k: dict({c: v / len(disp[k]) for c, v in acc[k].items()}, dispatches=len(disp[k])) for k in acc}
+    fetch = table("pmc_codec_FETCH_SIZE_counter_collection.csv", ("FETCH_SIZE",))
+    write = table("pmc_codec_WRITE_SIZE_counter_collection.csv", ("WRITE_SIZE",))
+    sq = table("pmc_codec_sq_counter_collection.csv", ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                                        "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"))
+    if not (fetch or write or sq):
+        return
+    out = {}
+    for k in sorted(set(fetch) | set(write) | set(sq)):
+        row = {}
+        if k in fetch:
+            row["FETCH_SIZE_KB"] = round(fetch[k]["FETCH_SIZE"], 1)
+        if k in write:
+            row["WRITE_SIZE_KB"] = round(write[k]["WRITE_SIZE"], 1)
+        if k in sq:
+            c = sq[k]
+            wc = c.get("SQ_WAVE_CYCLES", 0) or 1
+            row.update({"waves": round(c.get("SQ_WAVES", 0)), "valu": round(c.get("SQ_INSTS_VALU", 0)), "salu": round(c.get("SQ_INSTS_SALU", 0)),
+                        "lds": round(c.get("SQ_INSTS_LDS", 0)), "parked": round(c.get("SQ_WAIT_ANY", 0) / wc, 3),
+                        "issue_stall": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3), "issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+                        "dispatches": c["dispatches"]})
+        out[k] = row
+    doc = {"workload": "256 x 512x512 uint16 (bench batch 0), serial cct_encode_batch / cct_decode_batch calls, tools/prof_codec.py --reps 3",
+           "method": "rocprofv3 --kernel-trace --pmc <counter(s)> in separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set; values per dispatch, "
+                     "summed over the reported dimensions, averaged over the dispatches of a kernel; FETCH_SIZE / WRITE_SIZE in KB as counted",
+           "kernels": out}
+    with open(os.path.join(DST, f"{tag}_pmc_codec.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+    print(f"{tag}_pmc_codec.json: {len(out)} kernels")
 
 
 if __name__ == "__main__":

@@ -37,6 +37,17 @@ CCT_INF_PROF=1 timeout -k 10 200 python tools/prof_codec.py --reps 1 --what dec 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof2 -- python tools/prof_codec.py --reps 5 > $O/prof_codec_traced.log 2>&1
 find $O/prof2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/codec_serial_kernel_stats.csv
 rm -rf $O/prof2
+# the other device stages (DEFLATE chain, INFLATE, decode kernel): HBM traffic and SQ counters per kernel, serial encode / decode calls
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcc_$c -- python tools/prof_codec.py --reps 3 > $O/pmc_codec_$c.log 2>&1
+  find $O/pmcc_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/pmc_codec_${c}_counter_collection.csv
+  rm -rf $O/pmcc_$c
+done
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/pmcc_sq -- python tools/prof_codec.py --reps 3 > $O/pmc_codec_sq.log 2>&1
+find $O/pmcc_sq -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/pmc_codec_sq_counter_collection.csv
+rm -rf $O/pmcc_sq
+# phase stamps of the streaming kernel (diagnostic build of the same source)
+CCT_STREAM_STAMPS=1 timeout -k 10 200 python tools/prof_encode.py --paths 1 --reps 1 2>&1 | grep -A16 "stream stamps" | head -17 > $O/stream_stamps.log
 echo "pmc done"
 python -c "
 import json
