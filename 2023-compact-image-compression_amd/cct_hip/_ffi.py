@@ -8,7 +8,7 @@ import os
 import zlib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcompact_hip.so")
+LIB_PATH = os.environ.get("CCT_HIP_LIB") or os.path.join(_HERE, "libcompact_hip.so")  # CCT_HIP_LIB: tuning builds (tools/ab_build.sh)
 
 # error codes (include/compact_hip.h)
 OK, E_MAGIC, E_ZLIB, E_OVERFLOW, E_STREAM, E_SHAPE, E_CAP, E_NOMEM, E_DEVICE, E_ARG, E_MIXED = range(11)

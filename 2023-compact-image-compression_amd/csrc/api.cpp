@@ -436,21 +436,30 @@ void build_pipe_tables(const std::vector<int32_t> &O, int width, const std::vect
 		for (int px = 0; px < 4; px++) if (f >> px & 1) keep |= 0x80u << (8 * px);
 		ttab[f * 4 + 3] = keep;
 	}
-	// the first 64 traversal blocks of a tile (the look-ahead of the previous tile's mesh search) as 32 block pairs
+	// the first 64 traversal blocks of a tile (the look-ahead of the previous tile's mesh search): a 32x32-pixel quadrant, 8
+	// block rows of 4 block pairs.  Entry (row * 4 + pair) of htab is the pair's ptab word; the quadrant's origin inside the
+	// tile travels in the kernel arguments (tiles.qorg), so the rows of the look-ahead are requested without a table lookup
 	std::vector<uint32_t> htab((size_t)no * 32 * 2, 0);
 	for (int to = 0; to < no; to++) {
-		int cnt = 0;
+		int cnt = 0, r0 = 16, c0 = 8;
 		for (int lane = 0; lane < 128; lane++) {
 			const uint32_t *e = ptab.data() + ((size_t)to * 128 + lane) * 4;
 			const int ka = (int)(e[0] & 0xFF), kb = (int)((e[0] >> 16) & 0xFF);
 			if ((ka < 64) != (kb < 64)) return;
 			if (ka >= 64) continue;
-			if (cnt == 32) return;
-			htab[((size_t)to * 32 + cnt) * 2] = e[0];
-			htab[((size_t)to * 32 + cnt) * 2 + 1] = (uint32_t)((lane >> 3) * 4 * width + (lane & 7) * 8);
+			r0 = std::min(r0, lane >> 3); c0 = std::min(c0, lane & 7);
 			cnt++;
 		}
-		if (cnt != 32) return;
+		if (cnt != 32 || r0 > 8 || c0 > 4) return;
+		for (int lane = 0; lane < 128; lane++) {
+			const uint32_t *e = ptab.data() + ((size_t)to * 128 + lane) * 4;
+			if ((int)(e[0] & 0xFF) >= 64) continue;
+			const int r = (lane >> 3) - r0, c = (lane & 7) - c0;
+			if (r < 0 || r >= 8 || c < 0 || c >= 4) return;  // not an 8 x 4 rectangle of block pairs
+			htab[((size_t)to * 32 + r * 4 + c) * 2] = e[0];
+			htab[((size_t)to * 32 + r * 4 + c) * 2 + 1] = (uint32_t)((lane >> 3) * 4 * width + (lane & 7) * 8);
+		}
+		t.tiles.qorg[to] = (uint32_t)(r0 * 4 * width + c0 * 8);
 	}
 	if (hipMalloc(&t.d_ptab, ptab.size() * 4) != hipSuccess) return;
 	if (hipMalloc(&t.d_btab, btab.size() * 4) != hipSuccess) return;

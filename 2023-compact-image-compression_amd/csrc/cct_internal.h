@@ -58,6 +58,7 @@ struct PipeTiles {             // small per-shape tables carried IN the kernel a
 	                             // both (a byte array indexed by the tile became a vector load the next table lookup had to wait for)
 	uint32_t last[TILE_MAX_ORIENT];  // raster offset inside the tile of the tile's last traversal position
 	uint32_t mid[TILE_MAX_ORIENT];   // the same for position 2047 (the last pixel of the first half tile)
+	uint32_t qorg[TILE_MAX_ORIENT];  // raster offset inside the tile of the 32x32-pixel quadrant its first 64 traversal blocks cover
 	uint32_t geom[TILE_MAX_ORIENT * 2];  // region of half h of orientation o: bit 0 = vertical split (32x64 pixels), bits 8.. = first
 	                                     // block row (horizontal split) or first block-pair column (vertical split)
 };
@@ -97,8 +98,8 @@ struct StreamArgs {
 	EncArgs e;
 	PipeTiles tiles;
 	const uint32_t *ptab;        // as PipeArgs::ptab
-	const uint32_t *htab;        // n_orient * 32 entries of 2 dwords: the 32 block pairs that make up a tile's first 64 traversal blocks:
-	                             //   [0] as ptab[0], [1] raster offset inside the tile of the pair's 8x4-pixel region
+	const uint32_t *htab;        // n_orient * 32 entries of 2 dwords: the 32 block pairs (8 rows x 4) of the quadrant a tile's first 64
+	                             //   traversal blocks cover (origin: tiles.qorg): [0] as ptab[0], [1] raster offset of the pair inside the tile
 	const uint32_t *otab, *ttab; // as PipeArgs (ttab entry: selectors, token bytes, kept bits of the low bytes)
 	int n_tiles, row_pitch, gps, tpg; // gps: groups per slice, tpg: tiles per group
 	int dbg;                     // tuning runs only (CCT_STREAM_DBG): 1 no carry wait, 2 no look-back (results then invalid), 4 wrong group guess (results valid)

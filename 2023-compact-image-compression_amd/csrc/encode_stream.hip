@@ -263,10 +263,16 @@ __global__ void __launch_bounds__(64 * SW, 4) stream_kernel(StreamArgs a, uint64
 	auto issue_loads = [&](int gg, Loaded &L) {
 		const int t0_ = gg * SW, ntg_ = min(SW, NT - t0_);
 		if (wave == SW - 1) {
-			// the look-ahead: the first 64 traversal blocks of the next tile (32 block pairs, htab lists them; its entry is asked
-			// for first: the rows behind it wait for it only), and the pixel before the group
+			// the look-ahead: the first 64 traversal blocks of the next tile = one 32x32-pixel quadrant (8 rows of 4 block pairs,
+			// origin in the kernel arguments), and the pixel before the group
 			L.he = make_uint2(0u, 0u);
-			if (t0_ + ntg_ < NT) L.he = reinterpret_cast<const uint2 *>(a.htab)[TILE_ORIENT(a, t0_ + ntg_) * 32 + (lane & 31)];
+			if (t0_ + ntg_ < NT) {
+				const int to = TILE_ORIENT(a, t0_ + ntg_);
+				L.he = reinterpret_cast<const uint2 *>(a.htab)[to * 32 + (lane & 31)];
+				const uint16_t *p = img + TILE_ORG(a, t0_ + ntg_) + a.tiles.qorg[to] + (size_t)(((lane & 31) >> 2) * 4) * pitch + (lane & 3) * 8;
+#pragma unroll
+				for (int q = 0; q < 4; q++) L.hr[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
+			}
 			L.before = 0;
 			if (t0_ > 0) L.before = img[TILE_ORG(a, t0_ - 1) + a.tiles.last[TILE_ORIENT(a, t0_ - 1)]];
 		}
@@ -282,11 +288,6 @@ __global__ void __launch_bounds__(64 * SW, 4) stream_kernel(StreamArgs a, uint64
 				for (int q = 0; q < 4; q++) L.r[h][q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
 				L.e[h] = a.ptab[(size_t)(to * 128 + rl) * 4];
 			}
-		}
-		if (wave == SW - 1 && t0_ + ntg_ < NT) {
-			const uint16_t *p = img + TILE_ORG(a, t0_ + ntg_) + L.he.y;
-#pragma unroll
-			for (int q = 0; q < 4; q++) L.hr[q] = *reinterpret_cast<const u32x4 *>(p + (size_t)q * pitch);
 		}
 	};
 	const int g_guess = (int)((blockIdx.x / (gridDim.x / gps) + ((a.dbg & 4) ? 1u : 0u)) % (uint32_t)gps);   // (dbg 4: a wrong guess on purpose)
