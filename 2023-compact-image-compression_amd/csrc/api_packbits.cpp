@@ -51,8 +51,11 @@ static int packbits_batch(bool encode, const uint8_t *h_in, const uint64_t *h_of
 		for (int i = 0; i < n && e == hipSuccess; i++) {
 			if (h_status) h_status[i] = stv[i];
 			if (stv[i] && !first) first = (int)stv[i];
-			if (!stv[i] && h_out_sizes[i]) e = hipMemcpy(h_out + (size_t)i * out_stride, (const uint8_t *)d_out.p + (size_t)i * out_stride, h_out_sizes[i], hipMemcpyDeviceToHost);
+			// (asynchronous copies on the library's stream, one wait at the end: a synchronous hipMemcpy runs on the default stream and
+			// breaks a graph capture another thread may have open, profiles/r03_capture_vs_free.log)
+			if (!stv[i] && h_out_sizes[i]) e = hipMemcpyAsync(h_out + (size_t)i * out_stride, (const uint8_t *)d_out.p + (size_t)i * out_stride, h_out_sizes[i], hipMemcpyDeviceToHost, st);
 		}
+	{ const hipError_t e2 = hipStreamSynchronize(st); if (e == hipSuccess) e = e2; }
 	release();
 	if (e != hipSuccess) return fail(CCT_E_DEVICE, "packbits: %s", hipGetErrorString(e));
 	return first ? fail(first, "packbits decode: string rejected") : CCT_OK;

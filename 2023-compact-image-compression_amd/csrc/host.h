@@ -24,13 +24,18 @@ int fail(int code, const char *fmt, ...);
 			return ::cct::fail(CCT_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
 	} while (0)
 
-// Runtime operations that are rare and heavy -- stream capture and graph instantiation / destruction, device and pinned
-// allocations, stream creation -- never run next to another call of the library: every entry point that drives the device
-// holds `g_quiesce` shared from the moment it owns its slot (ApiCall), and those operations give it up and take it
-// exclusively (exclusive_section).  Order: slot mutex, then g_quiesce; a thread waiting for a slot holds neither.  (Two encode
-// calls, one capturing its graphs for the first time while the other allocated, were seen to hang inside the runtime about
-// once in ten runs of the concurrency test; steady-state launches, copies and synchronisations from several threads never
-// did, over thousands of overlapped steps.)
+// Runtime operations that are rare and heavy -- stream capture and graph instantiation / destruction, the per-shape table
+// builds (device allocations plus SYNCHRONOUS copies), workspace growth, stream creation -- never run next to another call of
+// the library: every entry point that drives the device holds `g_quiesce` shared from the moment it owns its slot (ApiCall), and
+// those operations give it up and take it exclusively (exclusive_section).  Order: slot mutex, then g_quiesce; a thread waiting
+// for a slot holds neither, and nobody waits for g_mu while it counts as a call in flight.
+// Why: round 2 saw two concurrent encode calls hang inside the runtime about once in ten runs, one of them capturing its graphs
+// for the first time.  Round 3 ran the suspects side by side without a lock (tools/debug/capture_vs_free.cpp,
+// profiles/r03_capture_vs_free.log): allocations, frees, pinned allocations and stream creation next to an open capture neither
+// stalled nor failed; a SYNCHRONOUS hipMemcpy (default stream) did -- hipStreamEndCapture then reports "capturing stream has
+// unjoined work" and the runtime dies.  The library's synchronous copies are the table builds (get_tables), which a second
+// thread could reach while the first one captured; they are inside the exclusive section now, and no steady-state path copies
+// synchronously any more.
 struct QuiesceLock {  // shared / exclusive with priority for the exclusive side (glibc's rwlock prefers readers: with three
 	std::mutex m;        // threads issuing calls back to back an exclusive section could wait for a long time)
 	std::condition_variable cv;
