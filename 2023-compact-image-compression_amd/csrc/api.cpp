@@ -69,9 +69,9 @@ struct EncSlot {
 	hipStream_t stream = nullptr;  // slot 0: the main stream
 	// the ~25 launches of one DEFLATE pass, captured once per argument set and replayed as a graph: fewer host
 	// calls and no dispatch gaps between the kernels when a decode shares the queue processor
-	hipGraph_t z_graph = nullptr;
-	hipGraphExec_t z_graph_exec = nullptr;
-	std::vector<uint8_t> z_graph_key;
+	struct ZGraph { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+	std::vector<ZGraph> z_graphs;  // a batch deflated in several passes has one argument set per pass (round 2 kept ONE graph and
+	uint64_t z_clock = 0;          // captured it again for every pass of such a batch: 5 ms per step at 512 x 1024^2)
 	// the memset + four launches of the transform+pack pipeline, likewise (a few argument sets: callers rotate batches)
 	struct PipeGraph { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
 	std::vector<PipeGraph> p_graphs;
@@ -725,8 +725,11 @@ int encode_payload_locked(EncSlot &E, hipStream_t st, const uint16_t *d_images, 
 		sa.spill_mask = (uint64_t *)E.e_lmask.p; sa.spill_idx = (uint16_t *)E.e_lidx.p; sa.pairrec = (uint8_t *)E.e_pairrec.p;
 		g_ctx.last_path = 3;
 		static const bool sstamps = getenv("CCT_STREAM_STAMPS") != nullptr;
-		if (sstamps) { HIP_TRY(launch_encode_stream(sa, n, st)); return CCT_OK; }
-		return launch_or_replay(&sa, sizeof sa, 4, [&]() { return launch_encode_stream(sa, n, st); });
+		(void)sstamps;
+		// two memsets and one kernel: launched plainly.  Replayed as a graph the three nodes took 0.20 ms in the bench against 0.15
+		// (profiles/r03_graph_ab.log): a graph pays between its nodes what it saves on the host, and there is nothing to save here
+		HIP_TRY(launch_encode_stream(sa, n, st));
+		return CCT_OK;
 	}
 	if (pipe_ok && g_ctx.use_tiles == 3) {
 		const int NT = tb->n_tiles;
@@ -824,22 +827,34 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 		std::vector<uint8_t> key(sizeof(DeflateArgs) + sizeof(int));
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
 		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
-		if (!E.z_graph_exec || key != E.z_graph_key) {
+		EncSlot::ZGraph *zg = nullptr;
+		for (auto &g : E.z_graphs) if (g.key == key) zg = &g;
+		if (!zg) {
 			const int crc = exclusive_section([&]() -> int {  // nothing else of the library runs during a capture (host.h)
-				if (E.z_graph_exec) { (void)hipGraphExecDestroy(E.z_graph_exec); E.z_graph_exec = nullptr; }
-				if (E.z_graph) { (void)hipGraphDestroy(E.z_graph); E.z_graph = nullptr; }
+				if (E.z_graphs.size() >= 4) {  // forget the least recently used argument set
+					size_t old = 0;
+					for (size_t i = 1; i < E.z_graphs.size(); i++) if (E.z_graphs[i].last_use < E.z_graphs[old].last_use) old = i;
+					if (E.z_graphs[old].exec) (void)hipGraphExecDestroy(E.z_graphs[old].exec);
+					if (E.z_graphs[old].graph) (void)hipGraphDestroy(E.z_graphs[old].graph);
+					E.z_graphs.erase(E.z_graphs.begin() + (long)old);
+				}
+				EncSlot::ZGraph g;
 				HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
 				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream);
-				hipError_t ce = hipStreamEndCapture(E.stream, &E.z_graph);
-				if (le != hipSuccess) return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le));
+				hipError_t ce = hipStreamEndCapture(E.stream, &g.graph);
+				if (le != hipSuccess) { if (g.graph) (void)hipGraphDestroy(g.graph); return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le)); }
 				HIP_TRY(ce);
-				HIP_TRY(hipGraphInstantiate(&E.z_graph_exec, E.z_graph, nullptr, nullptr, 0));
+				const hipError_t ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+				if (ie != hipSuccess) { (void)hipGraphDestroy(g.graph); return fail(CCT_E_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+				g.key = key;
+				E.z_graphs.push_back(std::move(g));
 				return CCT_OK;
 			});
 			if (crc) return crc;
-			E.z_graph_key = key;
+			zg = &E.z_graphs.back();
 		}
-		HIP_TRY(hipGraphLaunch(E.z_graph_exec, E.stream));
+		zg->last_use = ++E.z_clock;
+		HIP_TRY(hipGraphLaunch(zg->exec, E.stream));
 		return CCT_OK;
 	}
 	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream));
@@ -918,8 +933,7 @@ int cct_shutdown(void)
 		EncSlot &E = g_enc[k];
 		if (E.stream) (void)hipStreamSynchronize(E.stream);
 		if (E.stream_copy) (void)hipStreamSynchronize(E.stream_copy);
-		if (E.z_graph_exec) (void)hipGraphExecDestroy(E.z_graph_exec);
-		if (E.z_graph) (void)hipGraphDestroy(E.z_graph);
+		for (auto &g : E.z_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (auto &g : E.p_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (int i = 0; i < E.n_bufs; i++) E.all_bufs[i]->release();
 		hipEvent_t evs[] = {E.ev_k0, E.ev_k1, E.ev_z0, E.ev_z1, E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};

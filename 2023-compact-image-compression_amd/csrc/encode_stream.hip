@@ -207,6 +207,22 @@ __device__ __forceinline__ uint32_t emit16(const uint32_t x[8], uint32_t mb, uin
 	return o;
 }
 
+// the same for 16 pixels that all take one byte (the common case: smooth tissue, air): four dwords of 7-bit deltas, moved to
+// the byte phase of o by one v_perm each
+__device__ __forceinline__ void emit16_short(const uint32_t x[8], uint32_t o, LDS(uint8_t) *img)
+{
+	uint32_t P[4];
+#pragma unroll
+	for (int g = 0; g < 4; g++) P[g] = perm(x[2 * g + 1], x[2 * g], 0x06040200u) & 0x7F7F7F7Fu;
+	const uint32_t sel = 0x07060504u - (o & 3u) * 0x01010101u;   // byte i of a word: byte 4 + i - phase of {this dword : the one before}
+	LDS(uint32_t) *w = (LDS(uint32_t) *)(img + (o & ~3u));
+	lds_or(w, perm(P[0], 0u, sel));
+	lds_or(w + 1, perm(P[1], P[0], sel));
+	lds_or(w + 2, perm(P[2], P[1], sel));
+	lds_or(w + 3, perm(P[3], P[2], sel));
+	lds_or(w + 4, perm(0u, P[3], sel));
+}
+
 struct Hand {  // the three words a group publishes (8-byte agent-scope stores; bit 63 = valid; zeroed before every launch)
 	uint64_t carry;    // bits 0..62: which of the NEXT group's first 63 blocks this group's leaders have taken
 	uint64_t lastpx;   // bits 0..15: last pixel of this group's last emitted block group (the next group's predecessor pixel)
@@ -827,7 +843,9 @@ __global__ void __launch_bounds__(64 * SW, 4) stream_kernel(StreamArgs a, uint64
 	for (int s = 0; s < 4; s++) {
 		const int b = 256 * wave + 64 * s + lane;
 		const uint32_t r = active ? roles[b] : 0xFFu;
-		if (r == 0) (void)emit16(x[s], info[s] & 0xFFFFu, off[s], stg, ttab);
+		if (__all(r != 0 || (info[s] & 0xFFFFu) == 0)) {   // no two-byte token in the wave's 64 blocks
+			if (r == 0) emit16_short(x[s], off[s], stg);
+		} else if (r == 0) (void)emit16(x[s], info[s] & 0xFFFFu, off[s], stg, ttab);
 	}
 	if ((uint32_t)tid < npairs) {
 		uint32_t o = boff[p_i];
