@@ -139,6 +139,7 @@ struct Context {
 	int device = -1;
 	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
 	int use_graph = 1;
+	int compact_recs = 1;  // sort records that carry the first five string bytes (slices below 4 MiB; deflate_kernels.hip "Sort records")
 	int enc_slots = 1;  // option "encode_slots": encode batches on the device at a time.  Default 1: on two of the three boxes
 	                    // measured a second batch in flight cost more (each kernel slows down next to another batch's
 	                    // DEFLATE pass) than it filled (bench.py reports both settings: stages.other_encode_slot_setting)
@@ -809,6 +810,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
 	a.rec_in = (uint64_t *)E.z_vals_in.p; a.rec_out = (uint64_t *)E.z_vals_out.p;
+	a.pos_mask = (g_ctx.compact_recs && in_stride < ((size_t)1 << 22)) ? (1u << 22) - 1u : 0xFFFFFFFFu;
 	uint32_t *small = (uint32_t *)E.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
@@ -1773,6 +1775,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "device_deflate")) { g_ctx.device_deflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "deflate_compact_records")) { g_ctx.compact_recs = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) {
@@ -1796,6 +1799,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "device_deflate")) { *value = g_ctx.device_deflate; return CCT_OK; }
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
+	if (!strcmp(key, "deflate_compact_records")) { *value = g_ctx.compact_recs; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) { *value = g_ctx.inflate_lanes; return CCT_OK; }

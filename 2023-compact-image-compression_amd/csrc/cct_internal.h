@@ -154,7 +154,8 @@ struct BlockTables {
 };
 struct DeflateArgs {
 	const uint8_t *in; size_t in_stride; const uint32_t *in_sizes;  // token payloads (device)
-	uint64_t *rec_in, *rec_out;                                      // n * in_stride each: position | hash << 32, between / after the sort passes
+	uint64_t *rec_in, *rec_out;                                      // n * in_stride each: sort records (deflate_kernels.hip, "Sort records"), between / after the sort passes
+	uint32_t pos_mask;                                               // position bits of a record's lower word: 2^22 - 1 (compact records, in_stride < 4 MiB) or all 32
 	uint32_t *seg_begin, *seg_end;                                   // n
 	void *mr;                                                        // n * in_stride * 8 bytes
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each

@@ -98,21 +98,24 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	__syncthreads();
 	// digit histogram of this pass
 	if (FIRST) {
-		// eight loads in flight per lane (the rolled loop waited for every load before its LDS add: 170 memory round trips in a
-		// row per lane); the low hash byte depends on in[p + 1] and in[p + 2] only
+		// the low hash byte depends on in[p + 1] and in[p + 2] only.  A lane takes four positions from one dword-aligned 8-byte
+		// load, eight such loads in flight (the rolled loop waited for every load before its LDS add; byte-granular loads, one or
+		// two per position, made the address unit the bound of this pass)
 		constexpr int U = 8;
-		const uint32_t lastp = npos ? npos - 1 : 0;
-		for (uint32_t p0 = tid; p0 < npos; p0 += 1024 * U) {
-			uint32_t w[U];
+		const uint32_t qmax = (uint32_t)a.in_stride - 8u;
+		for (uint32_t q0 = (uint32_t)tid * 4u; q0 < npos; q0 += 4096 * U) {
+			uint2 w[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) w[u] = *reinterpret_cast<const uint2 *>(in + min(q0 + (uint32_t)u * 4096u, qmax));
 #pragma unroll
 			for (int u = 0; u < U; u++) {
-				const uint32_t p = min(p0 + (uint32_t)u * 1024u, lastp);
-				uint16_t x; __builtin_memcpy(&x, in + p + 1, 2);
-				w[u] = x;
-			}
+				const uint32_t q = q0 + (uint32_t)u * 4096u;
 #pragma unroll
-			for (int u = 0; u < U; u++)
-				if (p0 + (uint32_t)u * 1024u < npos) atomicAdd(&offs[(((w[u] & 255u) << 5) ^ (w[u] >> 8)) & 255u], 1u);
+				for (int k = 0; k < 4; k++) {
+					const uint32_t b12 = k < 3 ? __builtin_amdgcn_alignbyte(w[u].y, w[u].x, k + 1) : w[u].y;  // bytes q+k+1, q+k+2 in bits 0..15 (the shift is two bits wide)
+					if (q + k < npos) atomicAdd(&offs[(((b12 & 255u) << 5) ^ ((b12 >> 8) & 255u)) & 255u], 1u);
+				}
+			}
 		}
 	} else if (tid < NB) offs[tid] = a.sort_hist[(size_t)s * 128 + tid];
 	__syncthreads();
@@ -142,36 +145,73 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// in-order counter).  So: the index is clamped instead of tested, the raw values pass through an empty asm right before
 	// the stores (that is where the wait lands), and hash / position are derived after it.
 	const uint32_t last = npos ? npos - 1 : 0;
-	auto fetch = [&](uint32_t idx, uint32_t &ra, uint32_t &rb) {
-		const uint32_t j = min(idx, last);
-		if (FIRST) { uint16_t w; __builtin_memcpy(&w, in + j, 2); ra = w; rb = in[j + 2]; }  // the values as loaded: anything computed here is computed (and waited for) early
-		else { const uint64_t r = rec_src[j]; ra = (uint32_t)r; rb = (uint32_t)(r >> 32); }
+	// Pass A reads the input as aligned dwords: the 256 positions of a wave's tile need bytes [B, B + 260), lane l loads the dword
+	// at B + 4 l and everybody the one at B + 256; a position takes its two dwords from the lanes that hold them (ds_bpermute) and
+	// shifts its five bytes out.  (One byte-granular load per position and field was tried first: the pass went 0.44 -> 0.59 ms,
+	// the address unit handles such loads lane by lane.)  Bytes past the end of the slice are whatever the buffer holds: the hash
+	// of a valid position (p < L - 2) never sees them, and the match kernel does not use the compact fields of the last positions.
+	static_assert(!FIRST || E == 4, "pass A: one dword per lane covers the 256 positions of a wave's tile");
+#ifdef CCT_SORT_PROBE  // tuning builds only (results invalid)
+	const bool compact = false;
+#else
+	const bool compact = a.pos_mask != 0xFFFFFFFFu;
+#endif
+	const uint32_t dmax = (uint32_t)a.in_stride - 4u;
+	// tile_base = first element of this wave's 256; ra/rb = the values as loaded: anything computed here is computed (and waited for) early
+	auto fetch = [&](uint32_t tile_base, uint32_t (&ra)[E], uint32_t (&rb)[E]) {
+		if (FIRST) {
+			ra[0] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 4u * (uint32_t)lane, dmax));
+			ra[1] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 256u, dmax));
+			rb[0] = rb[1] = 0;
+		} else {
+#pragma unroll
+			for (int e = 0; e < E; e++) {
+				const uint64_t r = rec_src[min(tile_base + (uint32_t)(e * 64 + lane), last)];
+				ra[e] = (uint32_t)r; rb[e] = (uint32_t)(r >> 32);
+			}
+		}
 	};
-	auto finish = [&](uint32_t idx, uint32_t ra, uint32_t rb, uint32_t &h, uint32_t &p) {
-		if (FIRST) { h = (((ra & 255u) << 10) ^ ((ra >> 8) << 5) ^ rb) & 0x7FFFu; p = idx; }
-		else { h = rb; p = ra; }
-		if (idx >= npos) { h = 0; p = idx; }
+	// h = upper record word (hash in bits 0..14), p = lower record word (position in the bits of a.pos_mask): see "Sort records"
+	auto finish = [&](uint32_t tile_base, const uint32_t (&ra)[E], const uint32_t (&rb)[E], uint32_t (&h)[E], uint32_t (&p)[E]) {
+#pragma unroll
+		for (int e = 0; e < E; e++) {
+			const uint32_t idx = tile_base + (uint32_t)(e * 64 + lane);
+			if (FIRST) {
+				const int la = e * 16 + (lane >> 2);  // lane holding the dword of byte idx
+				const uint32_t da = (uint32_t)__builtin_amdgcn_ds_bpermute(la << 2, (int)ra[0]);
+				uint32_t db = (uint32_t)__builtin_amdgcn_ds_bpermute(((la + 1) & 63) << 2, (int)ra[0]);
+				if (la == 63) db = ra[1];
+				const uint32_t sh = (uint32_t)lane & 3u;
+				const uint32_t w = __builtin_amdgcn_alignbyte(db, da, sh);  // bytes idx .. idx + 3
+				const uint32_t b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u;
+				h[e] = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFFu; p[e] = idx;
+				if (compact) {
+					const uint32_t b4 = (db >> (8u * sh)) & 255u;
+					h[e] |= ((w >> 24) << 15) | (b4 << 23) | ((b0 >> 7) << 31); p[e] |= (b1 << 22) | (((b0 >> 5) & 3u) << 30);
+				}
+			}
+			else { h[e] = rb[e]; p[e] = ra[e]; }
+			if (idx >= npos) { h[e] = 0; p[e] = idx; }
+		}
 	};
 	uint32_t hn[E], pn[E];
 	{
 		uint32_t ra[E], rb[E];
-#pragma unroll
-		for (int e = 0; e < E; e++) fetch((uint32_t)(wave * 64 * E + e * 64 + lane), ra[e], rb[e]);
-#pragma unroll
-		for (int e = 0; e < E; e++) finish((uint32_t)(wave * 64 * E + e * 64 + lane), ra[e], rb[e], hn[e], pn[e]);
+		fetch((uint32_t)(wave * 64 * E), ra, rb);
+		finish((uint32_t)(wave * 64 * E), ra, rb, hn, pn);
 	}
 	for (uint32_t t0 = 0; t0 < npos; t0 += 1024 * E) {
 		uint32_t h[E], p[E], rk[E], ra[E], rb[E];
 		const uint32_t idx0 = t0 + (uint32_t)(wave * 64 * E + lane);
 #pragma unroll
 		for (int e = 0; e < E; e++) { h[e] = hn[e]; p[e] = pn[e]; }
-#pragma unroll
-		for (int e = 0; e < E; e++) fetch(idx0 + 1024 * E + e * 64, ra[e], rb[e]);
+		const uint32_t next_base = t0 + (uint32_t)(1024 * E + wave * 64 * E);
+		fetch(next_base, ra, rb);
 		for (int k = lane; k < NB; k += 64) wcnt[wave][k] = 0;
 #pragma unroll
 		for (int e = 0; e < E; e++) {
 			const bool valid = idx0 + e * 64 < npos;
-			const uint32_t d = FIRST ? (h[e] & 255u) : (h[e] >> 8);
+			const uint32_t d = FIRST ? (h[e] & 255u) : ((h[e] & 0x7FFFu) >> 8);
 			uint64_t same = __ballot(valid);  // lanes of this round with the same digit
 #pragma unroll
 			for (int b = 0; b < BITS; b++) {
@@ -184,7 +224,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			if (valid) {
 				before = wcnt[wave][d];  // equal digits of this wave's earlier rounds
 				if (rank == 0) wcnt[wave][d] = before + (uint32_t)__popcll(same);
-				if (FIRST) atomicAdd(&next_hist[h[e] >> 8], 1u);
+				if (FIRST) atomicAdd(&next_hist[(h[e] & 0x7FFFu) >> 8], 1u);
 			}
 			rk[e] = before + rank;
 		}
@@ -199,13 +239,12 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		}
 		lds_barrier();
 #pragma unroll
-		for (int e = 0; e < E; e++) asm volatile("" : "+v"(ra[e]), "+v"(rb[e]) :: "memory");
-#pragma unroll
-		for (int e = 0; e < E; e++) finish(idx0 + 1024 * E + e * 64, ra[e], rb[e], hn[e], pn[e]);
+		for (int e = 0; e < (FIRST ? 2 : E); e++) asm volatile("" : "+v"(ra[e]), "+v"(rb[e]) :: "memory");
+		finish(next_base, ra, rb, hn, pn);
 #pragma unroll
 		for (int e = 0; e < E; e++) {
 			if (idx0 + e * 64 < npos) {
-				const uint32_t d = FIRST ? (h[e] & 255u) : (h[e] >> 8);
+				const uint32_t d = FIRST ? (h[e] & 255u) : ((h[e] & 0x7FFFu) >> 8);
 				const uint32_t dst = wcnt[wave][d] + rk[e];
 				rec_dst[dst] = (uint64_t)p[e] | ((uint64_t)h[e] << 32);
 			}
@@ -332,6 +371,18 @@ __device__ __forceinline__ int common_prefix(const uint8_t *x, const uint8_t *y,
 	return len;
 }
 
+// Sort records.  Wide (any slice size): position | hash << 32.  Compact (slices below 4 MiB, a.pos_mask = 2^22 - 1): the record
+// also identifies the first five bytes b0..b4 of its string,
+//   lower word: position (22 bits) | b1 << 22 | (b0 >> 5 & 3) << 30        upper word: hash (15 bits) | b3 << 15 | b4 << 23 | (b0 >> 7) << 31
+// Two strings of one bucket start with the same three bytes exactly when b1 and the top three bits of b0 agree (the hash then
+// pins b2 and the rest of b0), so the match kernel decides every candidate whose match is shorter than five bytes -- nearly all
+// of them on token payloads -- from the records alone, which are read in sorted order (coalesced); before, every position paid
+// a scattered load for its own string and one per candidate.
+__device__ __forceinline__ uint32_t rec_hash(uint64_t r) { return (uint32_t)(r >> 32) & 0x7FFFu; }
+__device__ __forceinline__ uint32_t rec_pos(uint64_t r, uint32_t pos_mask) { return (uint32_t)r & pos_mask; }
+constexpr uint32_t COMPACT_POS_BITS = 22, COMPACT_POS_MASK = (1u << COMPACT_POS_BITS) - 1u;
+
+template <bool CMP>
 __global__ void dfl_match_kernel(DeflateArgs a, int n)
 {
 	int s; uint32_t part, nparts;
@@ -351,14 +402,58 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 		int kind = 0;  // 0: record written, 1: queue for the cooperative heavy pass, 2: queue for the run pass
 		if (i < npos) {
 			const uint64_t ri = recs[i];
-			const uint32_t p = (uint32_t)ri;
-			const uint32_t h = (uint32_t)(ri >> 32);
+			const uint32_t p = CMP ? (uint32_t)ri & COMPACT_POS_MASK : (uint32_t)ri;
+			const uint32_t h = rec_hash(ri);
 			const uint32_t lookahead = L - p;
 			const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
 			const uint32_t nil_q = nil_candidate(p, lookahead);
 			int best = 0, count = 0;
 			uint32_t best_q = 0;
 			const uint8_t *sp = in + p;
+			if (CMP && p + 8 <= L) {
+				// everything up to a match of four bytes from the records (see above); max_len >= 8 here
+				const uint32_t lo_i = (uint32_t)ri, hi_i = (uint32_t)(ri >> 32);
+				const uint32_t b1 = (lo_i >> 22) & 255u;
+				const bool in_run = h == (((b1 << 10) ^ (b1 << 5) ^ b1) & 0x7FFFu) && (((lo_i >> 30) | ((hi_i >> 31) << 2)) == (b1 >> 5));
+				uint32_t run_r = 0;
+				if (in_run) {
+					const uint32_t rw = rl[p];
+					run_r = rw & 0x7FFFu;
+					if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }
+					else kind = 2;
+				} else {
+					for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
+						const uint64_t rj = recs[j];
+						if (rec_hash(rj) != h) break;
+						if (count == LIGHT_STEPS) { kind = 1; break; }
+						const uint32_t lo_j = (uint32_t)rj, hi_j = (uint32_t)(rj >> 32);
+						const uint32_t q = lo_j & COMPACT_POS_MASK;
+						const uint32_t dist = p - q;
+						if (q == 0 || q == nil_q) break;
+						if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
+						const uint32_t x = hi_i ^ hi_j;  // hash bits are equal
+						if (best < max_len && (((lo_i ^ lo_j) >> 22) | (x >> 31)) == 0) {  // three bytes in common (less never counts)
+							int len;
+							if (x & 0x007F8000u) len = 3;
+							else if (x & 0x7F800000u) len = 4;
+							else if (best < 5 || in[q + best] == sp[best]) len = common_prefix(in + q, sp, 5, max_len);
+							else len = 0;
+							if (len > best) { best = len; best_q = q; }
+						}
+						count++;
+						if (best >= max_len) break;
+					}
+				}
+				MatchRec r;
+				if (kind == 0) {
+					r.len4096 = r.len1024 = (uint16_t)best;
+					r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
+				} else {
+					r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
+					r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
+				}
+				mr[p] = r;
+			} else {
 			// strings that START a run of three equal bytes share one bucket with every other position of
 			// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
 			// the list of run ends instead of walking the chain
@@ -377,9 +472,9 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 			} else {
 				for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
 					const uint64_t rj = recs[j];
-					if ((uint32_t)(rj >> 32) != h) break;
+					if (rec_hash(rj) != h) break;
 					if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
-					const uint32_t q = (uint32_t)rj;
+					const uint32_t q = CMP ? (uint32_t)rj & COMPACT_POS_MASK : (uint32_t)rj;
 					const uint32_t dist = p - q;
 					if (q == 0 || q == nil_q) break;                         // NIL ends the chain
 					if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
@@ -408,11 +503,8 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 				r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
 				r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
 			}
-#ifdef CCT_MATCH_PROBE  // tuning builds only (results invalid): what the scattered result store / the own-string load cost
-			if (CCT_MATCH_PROBE != 1) mr[p] = r; else if (r.len4096 == 0xFFFE) mr[p] = r;
-#else
 			mr[p] = r;
-#endif
+			}
 		}
 		// wave-aggregated appends: one atomic per wave and list
 		const uint64_t bh = __ballot(kind == 1), br = __ballot(kind == 2);
@@ -430,9 +522,9 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 // Wave-cooperative longest_match for one position whose chain is long: 64 candidates per step.
 // Returns the packed MatchRec (lo = len4096 | len1024 << 16, hi = dist4096 | dist1024 << 16), wave-uniform.
 __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint64_t *recs, uint32_t L,
-                                                   uint32_t i, uint32_t p, int lane, uint32_t &lo, uint32_t &hi)
+                                                   uint32_t i, uint32_t p, uint32_t pos_mask, int lane, uint32_t &lo, uint32_t &hi)
 {
-	const uint32_t h = (uint32_t)(recs[i] >> 32);
+	const uint32_t h = rec_hash(recs[i]);
 	const uint32_t lookahead = L - p;
 	const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
 	const uint32_t nil_q = nil_candidate(p, lookahead);
@@ -444,8 +536,8 @@ __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint
 	for (int r = 0; r < 64; r++) {  // 64 x 64 = max_chain_length 4096 candidates
 		const int64_t j = (int64_t)i - 1 - (int64_t)(r * 64 + lane);
 		const uint64_t rj = j >= 0 ? recs[j] : ~0ull;
-		const bool in_chain = j >= 0 && (uint32_t)(rj >> 32) == h;
-		const uint32_t q = in_chain ? (uint32_t)rj : 0u;
+		const bool in_chain = j >= 0 && rec_hash(rj) == h;
+		const uint32_t q = in_chain ? rec_pos(rj, pos_mask) : 0u;
 		const uint32_t dist = p - q;
 		const bool term = !in_chain || q == 0 || q == nil_q ||
 		                  ((r == 0 && lane == 0) ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST);
@@ -489,9 +581,9 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 	const int lane = threadIdx.x & 63;
 	for (uint32_t e = part * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += nparts * (blockDim.x >> 6)) {
 		const uint32_t i = heavy[e];
-		const uint32_t p = (uint32_t)recs[i];
+		const uint32_t p = rec_pos(recs[i], a.pos_mask);
 		uint32_t lo, hi;
-		coop_longest_match(in, recs, L, i, p, lane, lo, hi);
+		coop_longest_match(in, recs, L, i, p, a.pos_mask, lane, lo, hi);
 		if (lane == 0) mr[p] = make_uint2(lo, hi);
 	}
 }
@@ -606,8 +698,8 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 		// the four records a position can need depend on its sorted index only: requested together (clamped, not tested)
 		const uint64_t ri = recs[i];
 		const uint64_t r_head = recs[i >= 1 ? i - 1 : 0], r_1024 = recs[i >= 1024 ? i - 1024 : 0], r_4096 = recs[i >= 4096 ? i - 4096 : 0];
-		const uint32_t p = (uint32_t)ri;
-		const uint32_t h = (uint32_t)(ri >> 32);
+		const uint32_t p = rec_pos(ri, a.pos_mask);
+		const uint32_t h = rec_hash(ri);
 		const uint32_t lookahead = L - p;
 		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
 		const uint8_t b = in[p], b_prev = in[p >= 1 ? p - 1 : 0];
@@ -617,8 +709,8 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 		bool scan = true;
 		if (!has_prev) {  // chain head rules of deflate_slow / longest_match
 			const uint64_t rh = i >= 1 ? r_head : ~0ull;
-			const bool have_head = i >= 1 && (uint32_t)(rh >> 32) == h;
-			const uint32_t hq = have_head ? (uint32_t)rh : 0u;
+			const bool have_head = i >= 1 && rec_hash(rh) == h;
+			const uint32_t hq = have_head ? rec_pos(rh, a.pos_mask) : 0u;
 			if (!have_head || hq == 0 || hq == nil_candidate(p, lookahead) || p - hq > (uint32_t)MAX_DIST) scan = false;
 			else if (p - hq == (uint32_t)MAX_DIST) {  // only the head itself may sit at distance MAX_DIST
 				uint32_t len = 0;
@@ -632,8 +724,8 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 			const uint8_t c = ext_ok ? in[p + r] : 0;
 			const uint32_t qw = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1 : 1u;  // dist < MAX_DIST, q != NIL
 			uint32_t qmin4 = qw, qmin1 = qw;
-			if (i >= 4096 && (uint32_t)(r_4096 >> 32) == h) qmin4 = max(qmin4, (uint32_t)r_4096);
-			if (i >= 1024 && (uint32_t)(r_1024 >> 32) == h) qmin1 = max(qmin1, (uint32_t)r_1024);
+			if (i >= 4096 && rec_hash(r_4096) == h) qmin4 = max(qmin4, rec_pos(r_4096, a.pos_mask));
+			if (i >= 1024 && rec_hash(r_1024) == h) qmin1 = max(qmin1, rec_pos(r_1024, a.pos_mask));
 			uint32_t lo = 0, hi = nre;  // last run end <= p (none lies strictly inside p's own run)
 			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
@@ -1779,7 +1871,9 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over the upper part of rec_in, dead after the sort
 	const int gm = (int)std::min<size_t>(2048, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
-	hipLaunchKernelGGL(dfl_match_kernel, dim3(gm, n8), dim3(256), 0, st, a, n);
+	if (a.pos_mask == COMPACT_POS_MASK) hipLaunchKernelGGL(dfl_match_kernel<true>, dim3(gm, n8), dim3(256), 0, st, a, n);
+	else if (a.pos_mask == 0xFFFFFFFFu) hipLaunchKernelGGL(dfl_match_kernel<false>, dim3(gm, n8), dim3(256), 0, st, a, n);
+	else return hipErrorInvalidValue;
 	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);

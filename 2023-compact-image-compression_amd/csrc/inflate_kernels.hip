@@ -51,7 +51,10 @@ constexpr int INF_CHUNK = 4096;
 constexpr int LL_BITS = 12;
 constexpr int D_BITS = 10;
 constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24, K_TWO = 1u << 26;
-constexpr int SEG_BITS = 256;                 // compressed bits per lane and round
+#ifndef CCT_INF_SEG_BITS
+#define CCT_INF_SEG_BITS 256
+#endif
+constexpr int SEG_BITS = CCT_INF_SEG_BITS;    // compressed bits per lane and round
 constexpr int LANE_OUT_CAP = 16384;           // a lane stops (and ends the round) once it has produced this much
 constexpr int MLIST_CAP = 2048;               // LZ77 copies a round may hold (one lane alone: at most SEG_BITS / 2)
 constexpr uint32_t SEG_EOB = 1, SEG_BAD = 2, SEG_CUT = 4;
