@@ -89,7 +89,12 @@ struct EncSlot {
 	DevBuf h_stage;  // pinned host staging (payloads)
 	// device DEFLATE workspaces
 	DevBuf z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
-	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs;
+	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs, z_gen;
+	// match records are valid by tag (deflate_kernels.hip MatchRec): the device counter z_gen has run z_gen_passes times since
+	// the buffer z_mr_cleared (z_mr at that time) was last zeroed together with it
+	const void *z_mr_cleared = nullptr;
+	size_t z_mr_cleared_cap = 0;
+	unsigned z_gen_passes = 0;
 	float t_dev_deflate_ms = 0;
 	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // around the transform+pack stage
@@ -100,7 +105,7 @@ struct EncSlot {
 		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
 		               &e_spill, &e_tflag, &e_hand, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
 		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
-		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1]};
+		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1], &z_gen};
 		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
 		h_stage.pinned_host = true;
 	}
@@ -814,9 +819,19 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	uint32_t *small = (uint32_t *)E.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
+	// the tag of a pass must not meet a record of 16383 passes ago: clear records and counter well before it comes round (and
+	// whenever the buffer is new); a pass that failed on the way may have left the two counts a few apart, hence the margin
+	if ((rc = E.z_gen.ensure(256))) return rc;
+	if (E.z_mr_cleared != E.z_mr.p || E.z_mr_cleared_cap != E.z_mr.cap || E.z_gen_passes >= 16000u) {
+		HIP_TRY(hipMemsetAsync(E.z_mr.p, 0, E.z_mr.cap, E.stream));
+		HIP_TRY(hipMemsetAsync(E.z_gen.p, 0, 256, E.stream));
+		E.z_mr_cleared = E.z_mr.p; E.z_mr_cleared_cap = E.z_mr.cap; E.z_gen_passes = 0;
+	}
+	E.z_gen_passes++;
+	a.gen = (uint32_t *)E.z_gen.p;
 	a.mr = E.z_mr.p; a.heavy_list = (uint32_t *)E.z_rec.p; a.sym = (uint32_t *)E.z_sym.p;
-	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the half-sorted records are dead after the sort: 4 EB for the run list ...
-	a.run_len = (uint16_t *)((uint8_t *)E.z_vals_in.p + EB * 4);  // ... and 2 EB for the run lengths
+	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the half-sorted records are dead after the sort: 4 EB for the run list
+	a.run_len = (uint16_t *)E.z_sym.p;  // 2 EB, written before the sort and dead before the symbols are
 	a.rec32 = (uint32_t *)E.z_exitp.p; a.exit_pos = (uint32_t *)E.z_exitc.p; a.exit_cnt = (uint32_t *)E.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
 	a.blk_entry = (uint32_t *)E.z_bentry.p; a.blk_symbase = (uint32_t *)E.z_bsym.p;
 	a.blk_end = (uint32_t *)E.z_bend.p;

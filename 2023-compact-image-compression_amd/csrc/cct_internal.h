@@ -157,7 +157,8 @@ struct DeflateArgs {
 	uint64_t *rec_in, *rec_out;                                      // n * in_stride each: sort records (deflate_kernels.hip, "Sort records"), between / after the sort passes
 	uint32_t pos_mask;                                               // position bits of a record's lower word: 2^22 - 1 (compact records, in_stride < 4 MiB) or all 32
 	uint32_t *seg_begin, *seg_end;                                   // n
-	void *mr;                                                        // n * in_stride * 8 bytes
+	void *mr;                                                        // n * in_stride * 8 bytes: match records, valid where they carry the tag *gen
+	uint32_t *gen;                                                   // device counter of the passes run on this mr buffer, 1 .. 16383 (deflate_kernels.hip MatchRec)
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each
 	uint32_t *sort_hist;                                             // n * 128: histogram of hash >> 8 per slice (pass A -> pass B)
 	uint16_t *run_len;                                               // n * in_stride: equal bytes ahead (<= 258) | has_prev << 15

@@ -57,6 +57,33 @@ __constant__ uint16_t c_static_dcode[30];
 __device__ __forceinline__ int d_code(uint32_t dist) { return dist < 256 ? c_dist_code[dist] : c_dist_code[256 + (dist >> 7)]; }
 
 struct MatchRec { uint16_t len4096, len1024, dist4096, dist1024; };
+// Match records are only stored where there is something to say (a match of >= MIN_MATCH bytes): a record counts when it
+// carries the tag of the current pass -- 14 bits in the spare upper bits of the two length fields (lengths are <= 258), taken
+// from a device counter that dfl_offsets_kernel advances at the start of every pass (1 .. 16383; the host clears the buffer
+// before the counter would come round, api.cpp deflate_locked).  Writing a "no match" record for every position instead cost
+// 0.17 ms per batch (555 MB of stores), as much as the scattered stores it had saved in the match kernel.
+constexpr uint32_t GEN_MAX = 16383;
+__device__ __forceinline__ uint2 pack_match(uint32_t len4096, uint32_t len1024, uint32_t dist4096, uint32_t dist1024, uint32_t gen)
+{
+	return make_uint2((len4096 | ((gen & 127u) << 9)) | ((len1024 | ((gen >> 7) << 9)) << 16), dist4096 | (dist1024 << 16));
+}
+// The record of position p as the parse reads it: the stored one if it carries this pass's tag; else "no match" -- or, deep
+// inside a run (in[p-1] == in[p] and at least max_len equal bytes ahead), the chain head p-1 at the cap, which nobody stores:
+// rw = run-length word of p (dfl_run_len_kernel).
+__device__ __forceinline__ MatchRec checked_match(MatchRec r, uint32_t gen, uint32_t rw, uint32_t p, uint32_t L)
+{
+	const uint32_t tag = (uint32_t)(r.len4096 >> 9) | ((uint32_t)(r.len1024 >> 9) << 7);
+	const uint32_t lookahead = L - min(p, L);
+	const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
+	const bool maximal = (rw >> 15) && (rw & 0x7FFFu) >= max_len && p + 2 < L;
+	MatchRec o;
+	const bool ok = tag == gen;
+	o.len4096 = ok ? (uint16_t)(r.len4096 & 511u) : (uint16_t)(maximal ? max_len : 0u);
+	o.len1024 = ok ? (uint16_t)(r.len1024 & 511u) : (uint16_t)(maximal ? max_len : 0u);
+	o.dist4096 = ok ? r.dist4096 : (uint16_t)(maximal ? 1u : 0u);
+	o.dist1024 = ok ? r.dist1024 : (uint16_t)(maximal ? 1u : 0u);
+	return o;
+}
 
 // ------------------------------------------------------------------ 1. hash + sort by (hash, position)
 // The chain of a string = the earlier strings with the same 15-bit hash, most recent first (deflate.c
@@ -162,7 +189,8 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		if (FIRST) {
 			ra[0] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 4u * (uint32_t)lane, dmax));
 			ra[1] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 256u, dmax));
-			rb[0] = rb[1] = 0;
+#pragma unroll
+			for (int e = 0; e < E; e++) rb[e] = compact ? a.run_len[base + min(tile_base + (uint32_t)(e * 64 + lane), last)] : 0u;  // see finish
 		} else {
 #pragma unroll
 			for (int e = 0; e < E; e++) {
@@ -186,8 +214,11 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 				const uint32_t b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u;
 				h[e] = ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFFu; p[e] = idx;
 				if (compact) {
+					// bytes 3 and 4 -- or, for a string that starts with three equal bytes (those go to the run matcher, nobody
+					// compares their bytes 3 and 4), the run-length word of the position, which saves the match kernel a scattered load
 					const uint32_t b4 = (db >> (8u * sh)) & 255u;
-					h[e] |= ((w >> 24) << 15) | (b4 << 23) | ((b0 >> 7) << 31); p[e] |= (b1 << 22) | (((b0 >> 5) & 3u) << 30);
+					const uint32_t f16 = (b0 == b1 && b1 == b2) ? rb[e] : ((w >> 24) | (b4 << 8));
+					h[e] |= (f16 << 15) | ((b0 >> 7) << 31); p[e] |= (b1 << 22) | (((b0 >> 5) & 3u) << 30);
 				}
 			}
 			else { h[e] = rb[e]; p[e] = ra[e]; }
@@ -239,7 +270,7 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		}
 		lds_barrier();
 #pragma unroll
-		for (int e = 0; e < (FIRST ? 2 : E); e++) asm volatile("" : "+v"(ra[e]), "+v"(rb[e]) :: "memory");
+		for (int e = 0; e < E; e++) asm volatile("" : "+v"(ra[e]), "+v"(rb[e]) :: "memory");
 		finish(next_base, ra, rb, hn, pn);
 #pragma unroll
 		for (int e = 0; e < E; e++) {
@@ -382,6 +413,65 @@ __device__ __forceinline__ uint32_t rec_hash(uint64_t r) { return (uint32_t)(r >
 __device__ __forceinline__ uint32_t rec_pos(uint64_t r, uint32_t pos_mask) { return (uint32_t)r & pos_mask; }
 constexpr uint32_t COMPACT_POS_BITS = 22, COMPACT_POS_MASK = (1u << COMPACT_POS_BITS) - 1u;
 
+// longest_match over at most LIGHT_STEPS chain entries, strings read from the input (wide records, and the last seven positions
+// of a slice with compact ones).  kind: 0 = best/best_q hold the result, 1 = heavy (longer chain), 2 = starts a run (run_r).
+__device__ __forceinline__ void light_match_from_memory(const uint8_t *in, const uint64_t *recs, const uint16_t *rl, uint32_t pos_mask,
+                                                        uint32_t L, uint32_t i, uint32_t p, uint32_t h,
+                                                        int &kind, int &best, uint32_t &best_q, uint32_t &run_r)
+{
+	const uint32_t lookahead = L - p;
+	const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
+	const uint32_t nil_q = nil_candidate(p, lookahead);
+	int count = 0;
+	const uint8_t *sp = in + p;
+	// strings that START a run of three equal bytes share one bucket with every other position of
+	// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
+	// the list of run ends instead of walking the chain
+	// the first 8 bytes of the string decide most things; in hash order every access to the slice is its own
+	// L2 transaction, so the run-length word is only fetched for the strings that need it
+	const bool wide = p + 8 <= L;  // then max_len >= 8 and sp[0..7] is inside the input
+	uint64_t ow = 0;
+	if (wide) __builtin_memcpy(&ow, sp, 8);
+	const bool in_run = wide ? (((ow >> 8) ^ ow) & 0xFFFFu) == 0 : (sp[1] == sp[0] && sp[2] == sp[0]);
+	if (in_run) {
+		const uint32_t rw = rl[p];
+		run_r = rw & 0x7FFFu;  // >= 3, <= max_len by construction
+		if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
+		else kind = 2;
+		return;
+	}
+	for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
+		const uint64_t rj = recs[j];
+		if (rec_hash(rj) != h) break;
+		if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
+		const uint32_t q = rec_pos(rj, pos_mask);
+		const uint32_t dist = p - q;
+		if (q == 0 || q == nil_q) break;                         // NIL ends the chain
+		if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
+		const uint8_t *mp = in + q;
+		if (best < max_len) {                                    // only a longer match can replace the best
+			int len = 0;
+			if (wide) {  // one 8-byte load decides most candidates (the loads of mp are the uncoalesced ones)
+				if (best < 8 || mp[best] == sp[best]) {
+					uint64_t cw;
+					__builtin_memcpy(&cw, mp, 8);
+					const uint64_t d = cw ^ ow;
+					len = d ? (__ffsll((long long)d) - 1) >> 3 : common_prefix(mp, sp, 8, max_len);
+				}
+			} else if (mp[best] == sp[best]) len = common_prefix(mp, sp, 0, max_len);
+			if (len > best) { best = len; best_q = q; }
+		}
+		count++;
+		if (best >= max_len) break;                              // len >= nice_match
+	}
+}
+
+// v of the lane below; lane 0 takes `fill` (DPP wave_shr:1 -- every lane of the wave must be enabled where this is called)
+__device__ __forceinline__ uint32_t wave_shift_up(uint32_t v, uint32_t fill)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+
 template <bool CMP>
 __global__ void dfl_match_kernel(DeflateArgs a, int n)
 {
@@ -391,120 +481,82 @@ __global__ void dfl_match_kernel(DeflateArgs a, int n)
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	const size_t base = (size_t)s * a.in_stride;
 	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
-	const uint64_t *recs = a.rec_out + base;  // sorted (hash, position) records: position | hash << 32
-	MatchRec *mr = reinterpret_cast<MatchRec *>(a.mr) + base;
+	const uint64_t *recs = a.rec_out + base;  // sorted records, see "Sort records"
+	uint2 *mr = reinterpret_cast<uint2 *>(a.mr) + base;
 	uint32_t *heavy = a.heavy_list + base;
 	const uint16_t *rl = a.run_len + base;
 	const int lane = threadIdx.x & 63;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
+	const uint32_t gen = *a.gen;
 	for (uint32_t i0 = part * blockDim.x; i0 < npos; i0 += nparts * blockDim.x) {  // wave-uniform trip count
 		const uint32_t i = i0 + threadIdx.x;
+		const bool valid = i < npos;
 		int kind = 0;  // 0: record written, 1: queue for the cooperative heavy pass, 2: queue for the run pass
-		if (i < npos) {
-			const uint64_t ri = recs[i];
-			const uint32_t p = CMP ? (uint32_t)ri & COMPACT_POS_MASK : (uint32_t)ri;
-			const uint32_t h = rec_hash(ri);
+		int best = 0;
+		uint32_t best_q = 0, run_r = 0;
+		const uint64_t ri = recs[min(i, npos - 1)];
+		const uint32_t p = rec_pos(ri, CMP ? COMPACT_POS_MASK : 0xFFFFFFFFu);
+		const uint32_t h = rec_hash(ri);
+		bool from_memory = valid;
+		bool found = false;  // something to store (see MatchRec)
+		if (CMP) {
+			// The chain of sorted index i is i-1, i-2, ...: the records of the lanes below, then of the 64 indices before the wave.
+			// Both sit in registers (one coalesced load each) and move up one lane per step, so a step waits for nothing; with
+			// one load per step a wave paid a memory round trip for every entry of its longest chain.
+			const uint64_t rb = recs[min(i >= 64 ? i - 64 : 0u, npos - 1)];  // lane l: index (wave's first) + l - 64, unused where that is negative
+			const uint32_t lo_i = (uint32_t)ri, hi_i = (uint32_t)(ri >> 32), lo_b = (uint32_t)rb, hi_b = (uint32_t)(rb >> 32);
 			const uint32_t lookahead = L - p;
 			const int max_len = lookahead < (uint32_t)MAX_MATCH ? (int)lookahead : MAX_MATCH;
+			const bool fast = valid && p + 8 <= L;  // max_len >= 8; the compact fields of the record are those of the string
+			from_memory = valid && !fast;
 			const uint32_t nil_q = nil_candidate(p, lookahead);
-			int best = 0, count = 0;
-			uint32_t best_q = 0;
-			const uint8_t *sp = in + p;
-			if (CMP && p + 8 <= L) {
-				// everything up to a match of four bytes from the records (see above); max_len >= 8 here
-				const uint32_t lo_i = (uint32_t)ri, hi_i = (uint32_t)(ri >> 32);
-				const uint32_t b1 = (lo_i >> 22) & 255u;
-				const bool in_run = h == (((b1 << 10) ^ (b1 << 5) ^ b1) & 0x7FFFu) && (((lo_i >> 30) | ((hi_i >> 31) << 2)) == (b1 >> 5));
-				uint32_t run_r = 0;
-				if (in_run) {
-					const uint32_t rw = rl[p];
-					run_r = rw & 0x7FFFu;
-					if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }
-					else kind = 2;
-				} else {
-					for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
-						const uint64_t rj = recs[j];
-						if (rec_hash(rj) != h) break;
-						if (count == LIGHT_STEPS) { kind = 1; break; }
-						const uint32_t lo_j = (uint32_t)rj, hi_j = (uint32_t)(rj >> 32);
-						const uint32_t q = lo_j & COMPACT_POS_MASK;
-						const uint32_t dist = p - q;
-						if (q == 0 || q == nil_q) break;
-						if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
-						const uint32_t x = hi_i ^ hi_j;  // hash bits are equal
-						if (best < max_len && (((lo_i ^ lo_j) >> 22) | (x >> 31)) == 0) {  // three bytes in common (less never counts)
+			const uint32_t b1 = (lo_i >> 22) & 255u;
+			const bool in_run = h == (((b1 << 10) ^ (b1 << 5) ^ b1) & 0x7FFFu) && (((lo_i >> 30) | ((hi_i >> 31) << 2)) == (b1 >> 5));
+			if (fast && in_run) {  // the record carries the run-length word in place of bytes 3 and 4
+				const uint32_t rw = (hi_i >> 15) & 0xFFFFu;
+				run_r = rw & 0x7FFFu;
+				if (!((rw >> 15) && (int)run_r >= max_len)) kind = 2;  // else: chain head p-1 at the cap, which the parse knows from the run-length word (checked_match)
+			}
+			bool act = fast && !in_run;
+			// NIL (position 0, and the slide_hash quirk, which sits at distance MAX_DIST exactly) and the window as one bound on the
+			// candidate's position: the chain head may be MAX_DIST away, later entries must be closer
+			const uint32_t qmin_head = (p > (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST : 1u) + (nil_q != 0xFFFFFFFFu ? 1u : 0u);  // (nil_q, when there is one, is p - MAX_DIST)
+			const uint32_t qmin_rest = p >= (uint32_t)MAX_DIST ? p - (uint32_t)MAX_DIST + 1u : 1u;
+			const uint32_t steps_i = min(i, (uint32_t)LIGHT_STEPS + 1u);  // chain entries that exist at all
+			uint32_t clo = lo_i, chi = hi_i;
+#pragma unroll
+			for (int k = 1; k <= LIGHT_STEPS + 1; k++) {
+				// candidate i - k: shift the records up one lane, lane 0 takes index (wave's first) - k from the second register
+				clo = wave_shift_up(clo, (uint32_t)__builtin_amdgcn_readlane((int)lo_b, 64 - k));
+				chi = wave_shift_up(chi, (uint32_t)__builtin_amdgcn_readlane((int)hi_b, 64 - k));
+				if (!__any(act)) break;
+				const uint32_t x = hi_i ^ chi;
+				const uint32_t q = clo & COMPACT_POS_MASK;
+				// the chain ends: before the first record, at another hash, at NIL / outside the window
+				if ((uint32_t)k > steps_i || (x & 0x7FFFu) != 0 || q < (k == 1 ? qmin_head : qmin_rest)) act = false;
+				if (act) {
+					if (k == LIGHT_STEPS + 1) { kind = 1; act = false; }  // a 13th entry: heavy
+					else {
+						// three bytes in common (less never counts): then x holds the differences of bytes 3 and 4 only
+						if (best < max_len && (((lo_i ^ clo) >> 22) | (x >> 31)) == 0) {
 							int len;
 							if (x & 0x007F8000u) len = 3;
-							else if (x & 0x7F800000u) len = 4;
-							else if (best < 5 || in[q + best] == sp[best]) len = common_prefix(in + q, sp, 5, max_len);
+							else if (x) len = 4;
+							else if (best < 5 || in[q + best] == in[p + best]) len = common_prefix(in + q, in + p, 5, max_len);
 							else len = 0;
-							if (len > best) { best = len; best_q = q; }
+							if (len > best) { best = len; best_q = q; found = true; }
 						}
-						count++;
-						if (best >= max_len) break;
+						if (best >= max_len) act = false;  // len >= nice_match
 					}
 				}
-				MatchRec r;
-				if (kind == 0) {
-					r.len4096 = r.len1024 = (uint16_t)best;
-					r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
-				} else {
-					r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
-					r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
-				}
-				mr[p] = r;
-			} else {
-			// strings that START a run of three equal bytes share one bucket with every other position of
-			// every run of that byte (tens of thousands of entries); dfl_match_run_kernel evaluates them from
-			// the list of run ends instead of walking the chain
-			// the first 8 bytes of the string decide most things; in hash order every access to the slice is its own
-			// L2 transaction, so the run-length word is only fetched for the strings that need it
-			const bool wide = p + 8 <= L;  // then max_len >= 8 and sp[0..7] is inside the input
-			uint64_t ow = 0;
-			if (wide) __builtin_memcpy(&ow, sp, 8);
-			const bool in_run = wide ? (((ow >> 8) ^ ow) & 0xFFFFu) == 0 : (sp[1] == sp[0] && sp[2] == sp[0]);
-			uint32_t run_r = 0;
-			if (in_run) {
-				const uint32_t rw = rl[p];
-				run_r = rw & 0x7FFFu;  // >= 3, <= max_len by construction
-				if ((rw >> 15) && (int)run_r >= max_len) { best = max_len; best_q = p - 1; }  // chain head p-1 is already maximal
-				else kind = 2;
-			} else {
-				for (int64_t j = (int64_t)i - 1; j >= 0; j--) {
-					const uint64_t rj = recs[j];
-					if (rec_hash(rj) != h) break;
-					if (count == LIGHT_STEPS) { kind = 1; break; }           // heavy: finish cooperatively
-					const uint32_t q = CMP ? (uint32_t)rj & COMPACT_POS_MASK : (uint32_t)rj;
-					const uint32_t dist = p - q;
-					if (q == 0 || q == nil_q) break;                         // NIL ends the chain
-					if (count == 0 ? dist > (uint32_t)MAX_DIST : dist >= (uint32_t)MAX_DIST) break;
-					const uint8_t *mp = in + q;
-					if (best < max_len) {                                    // only a longer match can replace the best
-						int len = 0;
-						if (wide) {  // one 8-byte load decides most candidates (the loads of mp are the uncoalesced ones)
-							if (best < 8 || mp[best] == sp[best]) {
-								uint64_t cw;
-								__builtin_memcpy(&cw, mp, 8);
-								const uint64_t d = cw ^ ow;
-								len = d ? (__ffsll((long long)d) - 1) >> 3 : common_prefix(mp, sp, 8, max_len);
-							}
-						} else if (mp[best] == sp[best]) len = common_prefix(mp, sp, 0, max_len);
-						if (len > best) { best = len; best_q = q; }
-					}
-					count++;
-					if (best >= max_len) break;                              // len >= nice_match
-				}
 			}
-			MatchRec r;
-			if (kind == 0) {
-				r.len4096 = r.len1024 = (uint16_t)best;
-				r.dist4096 = r.dist1024 = (uint16_t)(best ? p - best_q : 0);
-			} else {  // sentinel carrying the sorted index (and, for run positions, the run length)
-				r.len4096 = 0xFFFF; r.len1024 = (uint16_t)run_r;
-				r.dist4096 = (uint16_t)(i & 0xFFFFu); r.dist1024 = (uint16_t)(i >> 16);
-			}
-			mr[p] = r;
-			}
+		}
+		if (from_memory) {
+			light_match_from_memory(in, recs, rl, CMP ? COMPACT_POS_MASK : 0xFFFFFFFFu, L, i, p, h, kind, best, best_q, run_r);
+			found = kind == 0 && best >= MIN_MATCH;
+		}
+		if (found && kind == 0) {  // shorter than MIN_MATCH never counts (match_of); queued positions are written by their kernels
+			mr[p] = pack_match((uint32_t)best, (uint32_t)best, p - best_q, p - best_q, gen);
 		}
 		// wave-aggregated appends: one atomic per wave and list
 		const uint64_t bh = __ballot(kind == 1), br = __ballot(kind == 2);
@@ -579,12 +631,13 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 	const uint32_t *heavy = a.heavy_list + base;
 	const uint32_t nheavy = a.heavy_count[s];
 	const int lane = threadIdx.x & 63;
+	const uint32_t gen = *a.gen;
 	for (uint32_t e = part * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nheavy; e += nparts * (blockDim.x >> 6)) {
 		const uint32_t i = heavy[e];
 		const uint32_t p = rec_pos(recs[i], a.pos_mask);
 		uint32_t lo, hi;
 		coop_longest_match(in, recs, L, i, p, a.pos_mask, lane, lo, hi);
-		if (lane == 0) mr[p] = make_uint2(lo, hi);
+		if (lane == 0) mr[p] = pack_match(lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16, gen);
 	}
 }
 
@@ -693,6 +746,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 	const uint32_t *re = a.run_ends + base;
 	const uint32_t *rl = re + (a.in_stride >> 1);
 	const uint32_t nre = a.run_end_count[s];
+	const uint32_t gen = *a.gen;
 	for (uint32_t e = part * blockDim.x + threadIdx.x; e < ndeep; e += nparts * blockDim.x) {
 		const uint32_t i = *(deep - e);
 		// the four records a position can need depend on its sorted index only: requested together (clamped, not tested)
@@ -703,7 +757,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 		const uint32_t lookahead = L - p;
 		const uint32_t max_len = lookahead < (uint32_t)MAX_MATCH ? lookahead : (uint32_t)MAX_MATCH;
 		const uint8_t b = in[p], b_prev = in[p >= 1 ? p - 1 : 0];
-		const uint32_t r = mr[p].x >> 16;  // run length from p, capped at max_len (left by dfl_match_kernel)
+		const uint32_t r = a.run_len[base + p] & 0x7FFFu;  // run length from p, capped at max_len
 		const bool has_prev = p >= 2 && b_prev == b;  // position 0 is NIL
 		uint32_t best4 = has_prev ? r : 0u, q4 = p - 1, best1 = best4, q1 = p - 1;
 		bool scan = true;
@@ -752,7 +806,7 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 				if (x - m <= qmin4) break;  // the run was cut by the limit: older runs are outside
 			}
 		}
-		mr[p] = make_uint2(best4 | (best1 << 16), (best4 ? p - q4 : 0u) | ((best1 ? p - q1 : 0u) << 16));
+		mr[p] = pack_match(best4, best1, best4 ? p - q4 : 0u, best1 ? p - q1 : 0u, gen);
 	}
 }
 
@@ -768,11 +822,11 @@ __device__ __forceinline__ void match_of(const MatchRec &r, uint32_t p, uint32_t
 	if (l > prev_len && l >= MIN_MATCH) { len = l; dist = d; }
 	if (len == MIN_MATCH && dist > TOO_FAR) len = 2;
 }
-__device__ __forceinline__ void match_at(const MatchRec *mr, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
+__device__ __forceinline__ void match_at(const MatchRec *mr, const uint16_t *rl, uint32_t gen, uint32_t p, uint32_t npos, int prev_len, int &len, int &dist)
 {
 	len = 2; dist = 0;
 	if (p >= npos || prev_len >= MAX_MATCH) return;
-	match_of(mr[p], p, npos, prev_len, len, dist);
+	match_of(checked_match(mr[p], gen, rl[p], p, npos + 2), p, npos, prev_len, len, dist);
 }
 
 __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
@@ -782,8 +836,10 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 	const size_t base = (size_t)s * a.in_stride;
 	const uint32_t npos = L >= MIN_MATCH ? L - 2 : 0;
 	const MatchRec *mr = reinterpret_cast<const MatchRec *>(a.mr) + base;
+	const uint16_t *rl = a.run_len + base;
 	const uint32_t nblk64 = (L + 63) / 64;
 	const int lane = threadIdx.x & 63;
+	const uint32_t gen = *a.gen;
 	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
 		const uint32_t p = wb * 64 + lane;
 		const uint32_t blk_end = wb * 64 + 64;
@@ -791,7 +847,10 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 		// the lane's own record and its right neighbour's (what the first deferral test reads) are requested together and
 		// without a branch: a load inside a conditional is waited for on the spot, which made them two round trips in a row
 		const uint32_t lastp = npos ? npos - 1 : 0;
-		const MatchRec r0 = mr[min(p, lastp)], r1 = mr[min(p + 1, lastp)];
+		const uint32_t pa = min(p, lastp), pb = min(p + 1, lastp);
+		const MatchRec m0 = mr[pa], m1 = mr[pb];
+		const uint32_t w0 = rl[pa], w1 = rl[pb];
+		const MatchRec r0 = checked_match(m0, gen, w0, pa, L), r1 = checked_match(m1, gen, w1, pb, L);
 		if (p < L) {
 			int len, dist;
 			match_of(r0, p, npos, 2, len, dist);
@@ -801,7 +860,7 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 				for (;;) {  // lazy evaluation: defer while the next position has a longer match
 					int l2, d2;
 					if (k == 0) match_of(r1, p + 1, npos, len, l2, d2);
-					else match_at(mr, p + k + 1, npos, len, l2, d2);
+					else match_at(mr, rl, gen, p + k + 1, npos, len, l2, d2);
 					if (l2 > len) { len = l2; dist = d2; k++; } else break;
 				}
 				rec = k | ((uint32_t)len << 8) | ((uint32_t)dist << 17);
@@ -1802,8 +1861,10 @@ __global__ void dfl_offsets2_kernel(DeflateArgs a, int n)
 
 __global__ void dfl_offsets_kernel(DeflateArgs a, int n)
 {
-	if (blockIdx.x == 0)
+	if (blockIdx.x == 0) {
 		for (int s = threadIdx.x; s < n; s += blockDim.x) { a.postloop_lit[s] = 0; a.heavy_count[s] = 0; a.deep_count[s] = 0; }
+		if (threadIdx.x == 0) *a.gen = *a.gen % GEN_MAX + 1u;  // tag of this pass's match records (see MatchRec)
+	}
 }
 
 }  // namespace
@@ -1866,11 +1927,15 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	(void)sort_temp; (void)sort_temp_bytes;
+	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);       // run-length words (pass A puts them into the records, the parse reads them)
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> rec_in by hash & 255
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> rec_out by hash >> 8
-	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);
-	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);  // writes over the upper part of rec_in, dead after the sort
-	const int gm = (int)std::min<size_t>(2048, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
+	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);         // writes over rec_in, dead after the sort
+	// wide records: one 256-lane block per 256 positions (more of them in flight hide the scattered accesses better than grid-stride
+	// loops); compact records: the kernel is bound by its instructions, and 256 blocks per slice with four turns each measured best
+	// (486 us against 499 / 510 with 128 / 512, profiles/r03_match_grid.log)
+	const int gm_cap = a.pos_mask == COMPACT_POS_MASK ? 256 : 2048;
+	const int gm = (int)std::min<size_t>(gm_cap, (a.in_stride + 255) / 256), n8 = (n + 7) & ~7;  // see xcd_slice()
 	if (a.pos_mask == COMPACT_POS_MASK) hipLaunchKernelGGL(dfl_match_kernel<true>, dim3(gm, n8), dim3(256), 0, st, a, n);
 	else if (a.pos_mask == 0xFFFFFFFFu) hipLaunchKernelGGL(dfl_match_kernel<false>, dim3(gm, n8), dim3(256), 0, st, a, n);
 	else return hipErrorInvalidValue;

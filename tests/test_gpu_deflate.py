@@ -56,6 +56,30 @@ def test_token_payloads(hip):
     _check(hip, blobs)
 
 
+def test_both_sort_record_layouts(hip):
+    """Slices below 4 MiB sort compact records (position, hash and the first five bytes of the string; the match kernel then
+    reads candidates from registers), larger ones the wide records of rounds 1-2: option "deflate_compact_records" = 0 forces
+    the wide layout on the same inputs, and a slice above the bound takes it by itself."""
+    from cct_hip import _ffi
+    from oracle import oracle
+    rng = np.random.default_rng(77)
+    blobs = [b"", b"abc", b"abcabcabcabc" * 10, b"y" * 259, b"z" * 70000, bytes(range(256)) * 3,
+             rng.integers(0, 3, 65274, dtype=np.uint8).tobytes(), rng.integers(0, 3, 98043, dtype=np.uint8).tobytes(),
+             rng.integers(0, 16, 120000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+             oracle.encode(gi.ct_phantom(0), deflate=False)[13:], oracle.encode(gi.load_slice("slice0671"), deflate=False)[13:]]
+    L = _ffi.lib()
+    try:
+        _ffi.check(L.cct_set_option(b"deflate_compact_records", 0))
+        _check(hip, blobs)
+    finally:
+        _ffi.check(L.cct_set_option(b"deflate_compact_records", 1))
+    _check(hip, blobs)
+    big = np.tile(np.frombuffer(oracle.encode(gi.ct_phantom(1), deflate=False)[13:], dtype=np.uint8), 18)[: (1 << 22) + 70001]
+    big = big.copy()
+    big[::4099] ^= 0x55  # not one period repeated
+    _check(hip, [big.tobytes(), blobs[-1]])
+
+
 def test_encode_batch_host_and_device_deflate_agree(hip):
     from cct_hip import _ffi
     L = _ffi.lib()
