@@ -144,6 +144,7 @@ struct Context {
 	int device = -1;
 	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
 	int use_graph = 1;
+	int decode_yields = 1;  // decode kernels issued next to an encode wait for the next transform+pack stage to end (cct_decode_batch)
 	int compact_recs = 1;  // sort records that carry the first five string bytes (slices below 4 MiB; deflate_kernels.hip "Sort records")
 	int enc_slots = 1;  // option "encode_slots": encode batches on the device at a time.  Default 1: on two of the three boxes
 	                    // measured a second batch in flight cost more (each kernel slows down next to another batch's
@@ -169,6 +170,9 @@ struct Context {
 	int last_inflate_lanes = 0;  // read-only option "last_inflate_lanes"
 };
 std::atomic<int> g_encodes_in_flight{0};
+// gate between the decode and the encode stream (sched_kernels.hip): device counters and what has been issued so far
+uint32_t *g_gate = nullptr;
+std::atomic<uint32_t> g_gate_stages_issued{0}, g_gate_passes_issued{0};
 struct EncodeInFlight {
 	EncodeInFlight() { g_encodes_in_flight.fetch_add(1, std::memory_order_relaxed); }
 	~EncodeInFlight() { g_encodes_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -273,6 +277,9 @@ int ensure_ctx(int device)
 		HIP_TRY(hipEventCreateWithFlags(&D.ev_ws, hipEventDisableTiming));
 	}
 	HIP_TRY(deflate_init_tables());  // __constant__ tables of the DEFLATE kernels, shared by both encode slots
+	HIP_TRY(hipMalloc(&g_gate, 256));
+	HIP_TRY(hipMemset(g_gate, 0, 256));
+	g_gate_stages_issued = 0; g_gate_passes_issued = 0;
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
 	if (g_ctx.zlib_threads <= 0) {
@@ -959,6 +966,7 @@ int cct_shutdown(void)
 		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
 	}
 	comm_release();
+	if (g_gate) { (void)hipFree(g_gate); g_gate = nullptr; }
 	for (auto &kv : g_ctx.luts) {
 		ShapeTables &t = kv.second;
 		void *ptrs[] = {t.d_lut, t.d_org, t.d_orient, t.d_pat, t.d_ptab, t.d_ptab2, t.d_btab, t.d_otab, t.d_ttab, t.d_htab};
@@ -1363,6 +1371,8 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	                           h_stats ? (cct_slice_stats *)E.e_stats.p : nullptr, nullptr);
 	if (rc) return rc;
 	HIP_TRY(hipEventRecord(E.ev_k1, E.stream));
+	g_gate_stages_issued.fetch_add(1, std::memory_order_relaxed);
+	HIP_TRY(launch_gate_bump(g_gate, E.stream));  // decode kernels waiting for this stage to be over may go (cct_decode_batch)
 	if (h_stats)
 		HIP_TRY(hipMemcpyAsync(h_stats, E.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, E.stream));
 	std::vector<uint32_t> psz(n);
@@ -1403,6 +1413,8 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 			                    (const uint32_t *)E.e_sizes.p + c0, nc, hdr13, zstride);
 			if (rc) return rc;
 			HIP_TRY(hipEventRecord(E.ev_z1, E.stream));
+			g_gate_passes_issued.fetch_add(1, std::memory_order_relaxed);
+			HIP_TRY(launch_gate_bump(g_gate + 1, E.stream));
 			uint32_t *osz = h_out_sizes + c0;
 			HIP_TRY(hipMemcpyAsync(osz, E.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, E.stream));
 			HIP_TRY(hipStreamSynchronize(E.stream));
@@ -1684,6 +1696,14 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		ia.offsets = (const uint64_t *)D.d_archoffs.p; ia.skip = 13;
 		ia.out = (uint8_t *)D.d_payload.p; ia.out_stride = stride;
 		ia.out_sizes = (uint32_t *)D.d_sizes.p; ia.status = (uint32_t *)D.d_zstatus.p;
+		// A decode issued while an encode batch is on the device is part of a pipeline (the bench: the decode of step k next to
+		// the encode of step k+1, with slack): its kernels are released when the next transform+pack stage has ended, so that
+		// they run next to that batch's sort and match kernels and not next to a tree or transform+pack kernel
+		// (sched_kernels.hip has the measurements).  The archive upload above does not wait.  Option "decode_yields" = 0
+		// launches at once.
+		if (g_ctx.decode_yields && g_encodes_in_flight.load(std::memory_order_relaxed) > 0)
+			HIP_TRY(launch_gate_wait(g_gate, g_gate_stages_issued.load(std::memory_order_relaxed) + 1u,
+			                         g_gate_passes_issued.load(std::memory_order_relaxed), 600u, 20000u, st));
 		HIP_TRY(hipEventRecord(D.ev_d0, st));
 		HIP_TRY(launch_inflate(ia, n, st, inflate_lanes_now()));
 		HIP_TRY(hipEventRecord(D.ev_d1, st));
@@ -1791,6 +1811,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "device_inflate")) { g_ctx.device_inflate = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_compact_records")) { g_ctx.compact_recs = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "decode_yields")) { g_ctx.decode_yields = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) {
@@ -1815,6 +1836,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "device_inflate")) { *value = g_ctx.device_inflate; return CCT_OK; }
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "deflate_compact_records")) { *value = g_ctx.compact_recs; return CCT_OK; }
+	if (!strcmp(key, "decode_yields")) { *value = g_ctx.decode_yields; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) { *value = g_ctx.inflate_lanes; return CCT_OK; }

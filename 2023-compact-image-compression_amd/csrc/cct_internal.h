@@ -177,6 +177,10 @@ hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes,
                        int exact, hipStream_t st);
 hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st);
 
+// ---- gate between the decode and the encode stream (sched_kernels.hip) ---------------------------
+hipError_t launch_gate_bump(uint32_t *word, hipStream_t st);
+hipError_t launch_gate_wait(const uint32_t *gate, uint32_t want_stage, uint32_t want_pass, uint32_t grace_us, uint32_t timeout_us, hipStream_t st);
+
 // ---- device INFLATE (inflate_kernels.hip) ----------------------------------------------------
 struct InflateArgs {
 	const uint8_t *in; uint64_t in_total;   // archive bytes on the device (padded to 16), total size

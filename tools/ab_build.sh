@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/2023-compact-image-compression_amd/csrc
 name=$1; file=$2; flags=$3
 mkdir -p $ROOT/build_ab/obj_$name
-for f in encode_kernels.hip encode_tiles.hip encode_pipe.hip encode_stream.hip decode_kernels.hip deflate_kernels.hip inflate_kernels.hip packbits_kernels.hip api.cpp api_comm.cpp api_packbits.cpp curve.cpp; do
+for f in encode_kernels.hip encode_tiles.hip encode_pipe.hip encode_stream.hip decode_kernels.hip deflate_kernels.hip inflate_kernels.hip packbits_kernels.hip sched_kernels.hip api.cpp api_comm.cpp api_packbits.cpp curve.cpp; do
   if [ "$f" == "$file" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c $C/$f -o $ROOT/build_ab/obj_$name/$f.o
   else
