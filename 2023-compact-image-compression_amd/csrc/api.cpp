@@ -87,6 +87,7 @@ struct EncSlot {
 	DevBuf e_toff, e_pairrec, e_spill, e_tflag;  // staged pipeline: tile offsets, meshed-pair records, difficult-list spill
 	DevBuf e_hand;                               // streaming kernel: hand-off words and tickets
 	DevBuf h_stage;  // pinned host staging (payloads)
+	DevBuf h_small[2];  // pinned landing place of a call's sizes / status / statistics (a copy to pageable memory blocks the host until it has happened)
 	// device DEFLATE workspaces
 	DevBuf z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
 	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs, z_gen;
@@ -95,9 +96,12 @@ struct EncSlot {
 	const void *z_mr_cleared = nullptr;
 	size_t z_mr_cleared_cap = 0;
 	unsigned z_gen_passes = 0;
-	float t_dev_deflate_ms = 0;
-	hipEvent_t ev_z0 = nullptr, ev_z1 = nullptr;  // around the device DEFLATE pass
-	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // around the transform+pack stage
+	// timing events of an encode call, two sets: with the slot handed on before the host has synchronised (encode_batch_impl,
+	// "queue ahead") the next call records its own while this one has not read its durations yet
+	hipEvent_t ev_k0s[2] = {nullptr, nullptr}, ev_k1s[2] = {nullptr, nullptr};  // around the transform+pack stage
+	hipEvent_t ev_z0s[2] = {nullptr, nullptr}, ev_z1s[2] = {nullptr, nullptr};  // around the device DEFLATE pass
+	hipEvent_t ev_small[2] = {nullptr, nullptr};                                // sizes and status have reached the host
+	unsigned call_parity = 0;
 	DevBuf *all_bufs[48];
 	int n_bufs = 0;
 	EncSlot()
@@ -105,9 +109,10 @@ struct EncSlot {
 		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
 		               &e_spill, &e_tflag, &e_hand, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
 		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
-		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1], &z_gen};
+		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1], &z_gen, &h_small[0], &h_small[1]};
 		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
 		h_stage.pinned_host = true;
+		h_small[0].pinned_host = h_small[1].pinned_host = true;
 	}
 	EncSlot(const EncSlot &) = delete;
 	EncSlot &operator=(const EncSlot &) = delete;
@@ -144,6 +149,7 @@ struct Context {
 	int device = -1;
 	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
 	int use_graph = 1;
+	int queue_ahead = 1;    // an encode call hands its slot on before it waits for the sizes (encode_batch_impl)
 	int decode_yields = 1;  // decode kernels issued next to an encode wait for the next transform+pack stage to end (cct_decode_batch)
 	int compact_recs = 1;  // sort records that carry the first five string bytes (slices below 4 MiB; deflate_kernels.hip "Sort records")
 	int enc_slots = 1;  // option "encode_slots": encode batches on the device at a time.  Default 1: on two of the three boxes
@@ -172,7 +178,7 @@ struct Context {
 std::atomic<int> g_encodes_in_flight{0};
 // gate between the decode and the encode stream (sched_kernels.hip): device counters and what has been issued so far
 uint32_t *g_gate = nullptr;
-std::atomic<uint32_t> g_gate_stages_issued{0}, g_gate_passes_issued{0};
+std::atomic<uint32_t> g_gate_passes_issued{0};
 struct EncodeInFlight {
 	EncodeInFlight() { g_encodes_in_flight.fetch_add(1, std::memory_order_relaxed); }
 	~EncodeInFlight() { g_encodes_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -207,6 +213,11 @@ void reset_ctx()
 // decode driven from two threads do not overwrite each other's numbers
 thread_local float tl_enc_kernel_ms = 0, tl_dec_kernel_ms = 0, tl_d2h_ms = 0, tl_deflate_ms = 0, tl_inflate_ms = 0, tl_h2d_ms = 0;
 std::mutex g_mu1;     // encode slot 1
+// A call that has handed its slot on before its files left the device ("queue ahead", encode_batch_impl) still owns one of the
+// slot's two packed-archive buffers until it has queued the copy out of it; the call after next waits here before packing into it.
+std::mutex g_pack_mu;
+std::condition_variable g_pack_cv;
+bool g_pack_busy[N_ENC_SLOTS][2] = {};
 std::mutex g_mu_dec[N_DEC_SLOTS];  // the decode slots; like g_mu / g_mu1 they outlive reset_ctx(), which replaces the slot objects
 std::mutex g_mu_lut;  // the per-shape table cache (taken after g_mu by encode, alone by decode)
 
@@ -261,10 +272,13 @@ int ensure_ctx(int device)
 		E.mu = k == 0 ? &g_mu : &g_mu1;
 		if (k == 0) E.stream = g_ctx.stream;
 		else HIP_TRY(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
-		HIP_TRY(hipEventCreate(&E.ev_k0));
-		HIP_TRY(hipEventCreate(&E.ev_k1));
-		HIP_TRY(hipEventCreate(&E.ev_z0));
-		HIP_TRY(hipEventCreate(&E.ev_z1));
+		for (int q = 0; q < 2; q++) {
+			HIP_TRY(hipEventCreate(&E.ev_k0s[q]));
+			HIP_TRY(hipEventCreate(&E.ev_k1s[q]));
+			HIP_TRY(hipEventCreate(&E.ev_z0s[q]));
+			HIP_TRY(hipEventCreate(&E.ev_z1s[q]));
+			HIP_TRY(hipEventCreateWithFlags(&E.ev_small[q], hipEventDisableTiming));
+		}
 	}
 	for (int k = 0; k < N_DEC_SLOTS; k++) {
 		DecSlot &D = g_dec[k];
@@ -279,7 +293,7 @@ int ensure_ctx(int device)
 	HIP_TRY(deflate_init_tables());  // __constant__ tables of the DEFLATE kernels, shared by both encode slots
 	HIP_TRY(hipMalloc(&g_gate, 256));
 	HIP_TRY(hipMemset(g_gate, 0, 256));
-	g_gate_stages_issued = 0; g_gate_passes_issued = 0;
+	g_gate_passes_issued = 0;
 	g_ctx.device = dev;
 	g_ctx.pid = getpid();
 	if (g_ctx.zlib_threads <= 0) {
@@ -960,7 +974,8 @@ int cct_shutdown(void)
 		for (auto &g : E.z_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (auto &g : E.p_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (int i = 0; i < E.n_bufs; i++) E.all_bufs[i]->release();
-		hipEvent_t evs[] = {E.ev_k0, E.ev_k1, E.ev_z0, E.ev_z1, E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};
+		hipEvent_t evs[] = {E.ev_k0s[0], E.ev_k1s[0], E.ev_z0s[0], E.ev_z1s[0], E.ev_k0s[1], E.ev_k1s[1], E.ev_z0s[1], E.ev_z1s[1],
+		                    E.ev_small[0], E.ev_small[1], E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 		if (E.stream_copy) (void)hipStreamDestroy(E.stream_copy);
 		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
@@ -1205,11 +1220,17 @@ struct FilesOut {
 
 // archive layout, whole batch, page-locked destination: pack into one of two device buffers, hand the copy to the copy
 // stream and give the slot back (lk) before waiting for it -- the next batch's kernels start while these files travel
-static int files_to_pinned_archive_async(FilesOut &f, uint8_t *h_dst, std::unique_lock<std::mutex> &lk, hipEvent_t *done)
+// first half: pack the files of a pass into one of the two device buffers (offsets computed on the device from the sizes, so
+// this can be queued right behind the DEFLATE pass, before the host knows the sizes -- the pack used to start a launch
+// latency after the host had read them); `cap` = what the buffer must hold
+static int pack_enqueue(EncSlot &E, int nc, size_t zstride, size_t cap, unsigned *slot_out)
 {
-	EncSlot &E = f.E;
 	int rc;
 	const unsigned slot = E.pack_slot++ & 1u;
+	{
+		std::unique_lock<std::mutex> pl(g_pack_mu);
+		g_pack_cv.wait(pl, [&] { return !g_pack_busy[&E - g_enc][slot]; });
+	}
 	if (!E.stream_copy) {
 		const int crc = exclusive_section([&]() -> int {
 			HIP_TRY(hipStreamCreateWithFlags(&E.stream_copy, hipStreamNonBlocking));
@@ -1222,18 +1243,30 @@ static int files_to_pinned_archive_async(FilesOut &f, uint8_t *h_dst, std::uniqu
 		});
 		if (crc) return crc;
 	}
-	const size_t cap = f.offs[f.nc] + 16;  // the pack kernel works in 16-byte units
 	if (E.z_packed2[slot].cap < cap) HIP_TRY(hipEventSynchronize(E.ev_copied[slot]));  // about to be reallocated
 	if ((rc = E.z_packed2[slot].ensure(cap))) return rc;
+	if ((rc = E.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
 	HIP_TRY(hipStreamWaitEvent(E.stream, E.ev_copied[slot], 0));  // the copy out of this buffer two calls ago
-	HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, f.zstride, (const uint32_t *)E.z_outsizes.p, f.nc,
+	HIP_TRY(launch_pack((const uint8_t *)E.z_out.p, zstride, (const uint32_t *)E.z_outsizes.p, nc,
 	                    (uint64_t *)E.z_packoffs.p, (uint8_t *)E.z_packed2[slot].p, 1, E.stream));
 	HIP_TRY(hipEventRecord(E.ev_pack[slot], E.stream));
+	*slot_out = slot;
+	return CCT_OK;
+}
+
+// archive layout, whole batch, page-locked destination: pack into one of two device buffers (unless pack_enqueue has done so:
+// packed_slot >= 0), hand the copy to the copy stream and give the slot back (the caller does) before waiting for it -- the
+// next batch's kernels start while these files travel
+static int files_to_pinned_archive_async(FilesOut &f, uint8_t *h_dst, int packed_slot, hipEvent_t *done)
+{
+	EncSlot &E = f.E;
+	int rc;
+	unsigned slot = (unsigned)packed_slot;
+	if (packed_slot < 0 && (rc = pack_enqueue(E, f.nc, f.zstride, f.offs[f.nc] + 16, &slot))) return rc;  // (the pack kernel works in 16-byte units)
 	HIP_TRY(hipStreamWaitEvent(E.stream_copy, E.ev_pack[slot], 0));
 	HIP_TRY(hipMemcpyAsync(h_dst, E.z_packed2[slot].p, f.exact, hipMemcpyDeviceToHost, E.stream_copy));
 	HIP_TRY(hipEventRecord(E.ev_copied[slot], E.stream_copy));
 	*done = E.ev_copied[slot];
-	(void)lk;
 	return CCT_OK;
 }
 
@@ -1365,20 +1398,32 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	if ((rc = E.e_stats.ensure((size_t)n * sizeof(cct_slice_stats)))) return rc;
 	// (running this stage on a stream of the highest priority while the other slot is in its DEFLATE pass was tried: the
 	// kernels took as long as without, waves already resident are not displaced)
-	HIP_TRY(hipEventRecord(E.ev_k0, E.stream));
+	const unsigned par = E.call_parity++ & 1u;
+	// queue ahead (see below): possible when the whole call can be queued without the host knowing a size
+	const bool qa = packed && defl && g_ctx.device_deflate && g_ctx.queue_ahead && (size_t)n * stride <= DEFLATE_PASS_BYTES &&
+	                is_pinned_host(h_out, 1);
+	uint32_t *l_psz = nullptr, *l_status = nullptr, *l_osz = nullptr;  // landing places in pinned memory
+	cct_slice_stats *l_stats = nullptr;
+	if (qa) {
+		if ((rc = E.h_small[par].ensure((size_t)n * (12 + sizeof(cct_slice_stats))))) return rc;
+		l_psz = (uint32_t *)E.h_small[par].p; l_status = l_psz + n; l_osz = l_status + n;
+		l_stats = (cct_slice_stats *)(l_osz + n);
+	}
+	const hipEvent_t ev_k0 = E.ev_k0s[par], ev_k1 = E.ev_k1s[par], ev_z0 = E.ev_z0s[par], ev_z1 = E.ev_z1s[par];
+	float t_dev_deflate_ms = 0;
+	HIP_TRY(hipEventRecord(ev_k0, E.stream));
 	rc = encode_payload_locked(E, E.stream, d_img, n, width, height, block_size, flags, eof_byte, (uint8_t *)E.e_payload.p, stride,
 	                           (uint32_t *)E.e_sizes.p, (uint32_t *)E.e_status.p,
 	                           h_stats ? (cct_slice_stats *)E.e_stats.p : nullptr, nullptr);
 	if (rc) return rc;
-	HIP_TRY(hipEventRecord(E.ev_k1, E.stream));
-	g_gate_stages_issued.fetch_add(1, std::memory_order_relaxed);
+	HIP_TRY(hipEventRecord(ev_k1, E.stream));
 	HIP_TRY(launch_gate_bump(g_gate, E.stream));  // decode kernels waiting for this stage to be over may go (cct_decode_batch)
 	if (h_stats)
-		HIP_TRY(hipMemcpyAsync(h_stats, E.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, E.stream));
+		HIP_TRY(hipMemcpyAsync(qa ? l_stats : h_stats, E.e_stats.p, (size_t)n * sizeof(cct_slice_stats), hipMemcpyDeviceToHost, E.stream));
 	std::vector<uint32_t> psz(n);
 	DrainOnExit drain(E.stream);  // until the first synchronisation below
-	HIP_TRY(hipMemcpyAsync(psz.data(), E.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
-	HIP_TRY(hipMemcpyAsync(h_status, E.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipMemcpyAsync(qa ? l_psz : psz.data(), E.e_sizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
+	HIP_TRY(hipMemcpyAsync(qa ? l_status : h_status, E.e_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
 	// With DEFLATE on the device and the whole batch in one pass the host does not need sizes or status before
 	// the DEFLATE kernels are queued (they read the sizes on the device; a payload cannot outgrow its stride):
 	// one host synchronisation less per batch.
@@ -1386,7 +1431,7 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 	if (!one_pass) {
 		HIP_TRY(hipStreamSynchronize(E.stream));
 		drain.disarm();
-		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, E.ev_k0, E.ev_k1));
+		HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, ev_k0, ev_k1));
 	}
 	uint8_t hdr13[13];
 	make_header13(hdr13, magic, width, height, channels, bytes_per_channel, flags);
@@ -1408,28 +1453,53 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 		} copies_in_flight{E};
 		for (int c0 = 0; c0 < n; c0 += chunk) {
 			const int nc = std::min(chunk, n - c0);
-			HIP_TRY(hipEventRecord(E.ev_z0, E.stream));
+			HIP_TRY(hipEventRecord(ev_z0, E.stream));
 			rc = deflate_locked(E, (const uint8_t *)E.e_payload.p + (size_t)c0 * stride, stride,
 			                    (const uint32_t *)E.e_sizes.p + c0, nc, hdr13, zstride);
 			if (rc) return rc;
-			HIP_TRY(hipEventRecord(E.ev_z1, E.stream));
+			HIP_TRY(hipEventRecord(ev_z1, E.stream));
 			g_gate_passes_issued.fetch_add(1, std::memory_order_relaxed);
 			HIP_TRY(launch_gate_bump(g_gate + 1, E.stream));
+			int packed_slot = -1;
+			if (qa) {  // the common pipelined case: pack queued behind the pass
+				unsigned ps = 0;
+				if ((rc = pack_enqueue(E, nc, zstride, (size_t)nc * zstride + 16, &ps))) return rc;
+				packed_slot = (int)ps;
+			}
 			uint32_t *osz = h_out_sizes + c0;
-			HIP_TRY(hipMemcpyAsync(osz, E.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, E.stream));
-			HIP_TRY(hipStreamSynchronize(E.stream));
+			HIP_TRY(hipMemcpyAsync(qa ? l_osz : osz, E.z_outsizes.p, (size_t)nc * 4, hipMemcpyDeviceToHost, E.stream));
+			// Queue ahead: everything this call needs from the slot is in the stream now, so the slot goes to the next call
+			// BEFORE the host waits for the sizes: that call's kernels are queued behind this one's while they run, and the
+			// device no longer idles for a launch latency between one batch's pack and the next batch's first kernel and
+			// again before its DEFLATE graph (0.2 ms of a 4.2 ms step, profiles/r03_bench_timeline.log).  From here on the
+			// call touches its own events, its packed buffer (g_pack_busy) and the copy stream only.
+			struct PackOwner {
+				int e = -1; unsigned slot = 0;
+				void release() { if (e >= 0) { { std::lock_guard<std::mutex> pl(g_pack_mu); g_pack_busy[e][slot] = false; } g_pack_cv.notify_all(); e = -1; } }
+				~PackOwner() { release(); }
+			} pack_owner;
+			const bool queue_ahead = qa;
+			if (queue_ahead) {
+				HIP_TRY(hipEventRecord(E.ev_small[par], E.stream));
+				{ std::lock_guard<std::mutex> pl(g_pack_mu); g_pack_busy[&E - g_enc][packed_slot] = true; }
+				pack_owner.e = (int)(&E - g_enc); pack_owner.slot = (unsigned)packed_slot;
+				lk.unlock();
+				HIP_TRY(hipEventSynchronize(E.ev_small[par]));
+				memcpy(psz.data(), l_psz, (size_t)n * 4); memcpy(h_status, l_status, (size_t)n * 4); memcpy(osz, l_osz, (size_t)nc * 4);
+				if (h_stats) memcpy(h_stats, l_stats, (size_t)n * sizeof(cct_slice_stats));
+			} else HIP_TRY(hipStreamSynchronize(E.stream));
 			drain.disarm();  // nothing queued targets this frame any more (later chunks copy into caller memory and synchronise at once)
-			HIP_TRY(hipEventElapsedTime(&E.t_dev_deflate_ms, E.ev_z0, E.ev_z1));
+			HIP_TRY(hipEventElapsedTime(&t_dev_deflate_ms, ev_z0, ev_z1));
 			if (one_pass) {
-				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, E.ev_k0, E.ev_k1));
+				HIP_TRY(hipEventElapsedTime(&tl_enc_kernel_ms, ev_k0, ev_k1));
 				for (int i = 0; i < n; i++)
 					if (h_status[i] & CCT_ST_CAP) return fail(CCT_E_CAP, "slice %d overflowed its payload stride", i);
 			}
-			tl_deflate_ms += E.t_dev_deflate_ms;
+			tl_deflate_ms += t_dev_deflate_ms;
 			const double t_c0 = now_ms();
 			FilesOut f{E, nc, osz, zstride, 0, std::vector<size_t>(nc + 1, 0)};
 			for (int i = 0; i < nc; i++) { f.exact += osz[i]; f.offs[i + 1] = f.offs[i] + (((size_t)osz[i] + 15) & ~(size_t)15); }
-			if ((rc = E.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
+			if (packed_slot < 0 && (rc = E.z_packoffs.ensure((size_t)(nc + 1) * 8))) return rc;
 			if (!packed) {
 				if ((rc = files_to_strided(f, h_out + (size_t)c0 * out_stride, out_stride))) return rc;
 				tl_d2h_ms += (float)(now_ms() - t_c0);
@@ -1443,14 +1513,15 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				// page-locked archive: the files of this pass leave on the copy stream while the next pass (or, after the last
 				// one, the next batch) already runs its kernels
 				hipEvent_t done = nullptr;
-				if ((rc = files_to_pinned_archive_async(f, h_out + at, lk, &done))) return rc;
+				if ((rc = files_to_pinned_archive_async(f, h_out + at, packed_slot, &done))) return rc;
+				pack_owner.release();  // the copy out of the buffer is queued: the call after next may pack into it
 				copies_in_flight.armed = true;
 				tl_d2h_ms += (float)(now_ms() - t_c0);
 				if (c0 + nc < n) continue;
 				if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
-				const float t_defl = E.t_dev_deflate_ms;
+				const float t_defl = t_dev_deflate_ms;
 				const double t_unlock = now_ms();
-				lk.unlock();  // the slot is free for the next batch; only the copy stream still works for this one
+				if (lk.owns_lock()) lk.unlock();  // the slot is free for the next batch; only the copy stream still works for this one
 				HIP_TRY(hipEventSynchronize(done));
 				copies_in_flight.armed = false;
 				if (getenv("CCT_TRACE"))
@@ -1459,12 +1530,13 @@ static int encode_batch_impl(const uint16_t *images, int images_on_device, int n
 				tl_d2h_ms += (float)(now_ms() - t_c0);  // (no lock: a float for cct_last_timings)
 				return CCT_OK;
 			}
+			if (queue_ahead) return fail(CCT_E_ARG, "the archive buffer is page-locked at its start but not over the %zu bytes of this batch", f.exact);
 			double t_c1 = t_c0;
 			if ((rc = files_to_archive(f, h_out + at, &t_c1))) return rc;
 			tl_d2h_ms += (float)(now_ms() - t_c0);
 			if (getenv("CCT_TRACE"))
 				fprintf(stderr, "[cct] encode n=%d: deflate %.2f ms, pack+d2h %.2f ms, host scatter %.2f ms (%zu bytes)\n", nc,
-				        E.t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, f.exact);
+				        t_dev_deflate_ms, t_c1 - t_c0, now_ms() - t_c1, f.exact);
 		}
 		if (h_payload_sizes) memcpy(h_payload_sizes, psz.data(), (size_t)n * 4);
 		return CCT_OK;
@@ -1702,8 +1774,7 @@ int cct_decode_batch(const uint8_t *h_files, const uint64_t *h_offsets, int n, i
 		// (sched_kernels.hip has the measurements).  The archive upload above does not wait.  Option "decode_yields" = 0
 		// launches at once.
 		if (g_ctx.decode_yields && g_encodes_in_flight.load(std::memory_order_relaxed) > 0)
-			HIP_TRY(launch_gate_wait(g_gate, g_gate_stages_issued.load(std::memory_order_relaxed) + 1u,
-			                         g_gate_passes_issued.load(std::memory_order_relaxed), 600u, 20000u, st));
+			HIP_TRY(launch_gate_wait(g_gate, g_gate_passes_issued.load(std::memory_order_relaxed), 600u, 20000u, st));
 		HIP_TRY(hipEventRecord(D.ev_d0, st));
 		HIP_TRY(launch_inflate(ia, n, st, inflate_lanes_now()));
 		HIP_TRY(hipEventRecord(D.ev_d1, st));
@@ -1812,6 +1883,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "deflate_graph")) { g_ctx.use_graph = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "deflate_compact_records")) { g_ctx.compact_recs = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "decode_yields")) { g_ctx.decode_yields = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "queue_ahead")) { g_ctx.queue_ahead = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) {
@@ -1837,6 +1909,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "deflate_graph")) { *value = g_ctx.use_graph; return CCT_OK; }
 	if (!strcmp(key, "deflate_compact_records")) { *value = g_ctx.compact_recs; return CCT_OK; }
 	if (!strcmp(key, "decode_yields")) { *value = g_ctx.decode_yields; return CCT_OK; }
+	if (!strcmp(key, "queue_ahead")) { *value = g_ctx.queue_ahead; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) { *value = g_ctx.inflate_lanes; return CCT_OK; }

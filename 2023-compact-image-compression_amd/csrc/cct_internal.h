@@ -179,7 +179,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 
 // ---- gate between the decode and the encode stream (sched_kernels.hip) ---------------------------
 hipError_t launch_gate_bump(uint32_t *word, hipStream_t st);
-hipError_t launch_gate_wait(const uint32_t *gate, uint32_t want_stage, uint32_t want_pass, uint32_t grace_us, uint32_t timeout_us, hipStream_t st);
+hipError_t launch_gate_wait(const uint32_t *gate, uint32_t want_pass, uint32_t grace_us, uint32_t timeout_us, hipStream_t st);
 
 // ---- device INFLATE (inflate_kernels.hip) ----------------------------------------------------
 struct InflateArgs {

@@ -7,7 +7,7 @@
 // 1.59 instead of 0.73 ms beside the INFLATE and decode kernels, the Adler kernel 118 instead of 23 us; both sort passes
 // and the match kernel lose 0 to 10 %.  So the decode kernels of a call are released when the NEXT transform+pack stage has
 // ended -- they then run next to the sort and match kernels of that batch and are through before its tree kernel starts.
-// "Next" is a launch that has not happened when the decode call is made, so the gate is a counter in device memory:
+// "Next" is a launch that may not have happened when the decode call is made, so the gate is a counter in device memory:
 //   gate[0]  transform+pack stages that have ended      gate[1]  DEFLATE passes that have ended
 // bumped by one-lane kernels on the encode stream, waited for by a one-wave kernel on the decode stream.  When every
 // pass that had been issued at the time of the decode call has ended and no new stage follows within `grace`, the wait
@@ -25,10 +25,12 @@ __global__ void gate_bump_kernel(uint32_t *word)
 }
 
 // ticks of the constant 100 MHz counter (s_memrealtime)
-__global__ void gate_wait_kernel(const uint32_t *gate, uint32_t want_stage, uint32_t want_pass, uint32_t grace, uint32_t timeout)
+__global__ void gate_wait_kernel(const uint32_t *gate, uint32_t want_pass, uint32_t grace, uint32_t timeout)
 {
 	if (threadIdx.x != 0) return;
 	const uint64_t t0 = wall_clock64();
+	// the next stage to END after this kernel has started (the host may have queued it long ago: encode calls queue ahead)
+	const uint32_t want_stage = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 	uint64_t t_pass = 0;
 	for (;;) {
 		const uint32_t stage = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -52,9 +54,9 @@ hipError_t launch_gate_bump(uint32_t *word, hipStream_t st)
 	return hipGetLastError();
 }
 
-hipError_t launch_gate_wait(const uint32_t *gate, uint32_t want_stage, uint32_t want_pass, uint32_t grace_us, uint32_t timeout_us, hipStream_t st)
+hipError_t launch_gate_wait(const uint32_t *gate, uint32_t want_pass, uint32_t grace_us, uint32_t timeout_us, hipStream_t st)
 {
-	hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, st, gate, want_stage, want_pass, grace_us * 100u, timeout_us * 100u);
+	hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, st, gate, want_pass, grace_us * 100u, timeout_us * 100u);
 	return hipGetLastError();
 }
 

@@ -235,7 +235,8 @@ int cct_last_timings(float *out6);
 /* Options: "encode_slots" / "decode_slots" (1 or 2 batches on the device at a time), "device_deflate" / "device_inflate"
  * (0: that stage on the host thread team of "zlib_threads" threads), "inflate_lanes" (lanes per stream of the INFLATE kernel:
  * 256, 512, or 0 = 512 unless an encode call is in flight when the decode starts; "last_inflate_lanes" reads back the choice),
- * "tile_path", "deflate_graph", "wg_threads", "pipe_tpw", "pipe_timing" (kernel choice and tuning). */
+ * "tile_path", "stream_tpg", "deflate_graph", "deflate_compact_records", "wg_threads", "pipe_tpw", "pipe_timing" (kernel choice and
+ * tuning), "decode_yields" / "queue_ahead" (scheduling of pipelined calls; 0 switches them off). */
 int cct_set_option(const char *key, int value);
 int cct_get_option(const char *key, int *value);
 
