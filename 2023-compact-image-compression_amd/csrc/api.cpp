@@ -823,7 +823,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	if ((rc = E.z_exitc.ensure(EB * 4))) return rc;
 	if ((rc = E.z_bentry.ensure(EB / 64 * 4))) return rc;
 	if ((rc = E.z_bsym.ensure(EB / 64 * 4))) return rc;
-	if ((rc = E.z_small.ensure((size_t)n * (9 + 128) * 4))) return rc;
+	if ((rc = E.z_small.ensure((size_t)n * (9 + 384) * 4))) return rc;
 	if ((rc = E.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
 	if ((rc = E.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
 	if ((rc = E.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;

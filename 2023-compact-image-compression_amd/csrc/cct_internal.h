@@ -160,7 +160,7 @@ struct DeflateArgs {
 	void *mr;                                                        // n * in_stride * 8 bytes: match records, valid where they carry the tag *gen
 	uint32_t *gen;                                                   // device counter of the passes run on this mr buffer, 1 .. 16383 (deflate_kernels.hip MatchRec)
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each
-	uint32_t *sort_hist;                                             // n * 128: histogram of hash >> 8 per slice (pass A -> pass B)
+	uint32_t *sort_hist;                                             // n * 384: per slice the histograms of hash & 255 and of hash >> 8 (dfl_run_len_kernel -> sort passes)
 	uint16_t *run_len;                                               // n * in_stride: equal bytes ahead (<= 258) | has_prev << 15
 	uint32_t *rec32, *exit_pos, *exit_cnt;                           // n * in_stride each
 	uint32_t *blk_entry, *blk_symbase;                               // n * in_stride / 64

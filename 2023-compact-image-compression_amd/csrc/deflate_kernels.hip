@@ -107,7 +107,6 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	constexpr int BITS = FIRST ? 8 : 7, NB = 1 << BITS;
 	__shared__ uint32_t offs[256];
 	__shared__ uint32_t wcnt[16][NB];
-	__shared__ uint32_t next_hist[128];
 	const int s = blockIdx.x;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
@@ -121,30 +120,10 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 	if (tid < 256) offs[tid] = 0;
-	if (tid < 128) next_hist[tid] = 0;
 	__syncthreads();
-	// digit histogram of this pass
-	if (FIRST) {
-		// the low hash byte depends on in[p + 1] and in[p + 2] only.  A lane takes four positions from one dword-aligned 8-byte
-		// load, eight such loads in flight (the rolled loop waited for every load before its LDS add; byte-granular loads, one or
-		// two per position, made the address unit the bound of this pass)
-		constexpr int U = 8;
-		const uint32_t qmax = (uint32_t)a.in_stride - 8u;
-		for (uint32_t q0 = (uint32_t)tid * 4u; q0 < npos; q0 += 4096 * U) {
-			uint2 w[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) w[u] = *reinterpret_cast<const uint2 *>(in + min(q0 + (uint32_t)u * 4096u, qmax));
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const uint32_t q = q0 + (uint32_t)u * 4096u;
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint32_t b12 = k < 3 ? __builtin_amdgcn_alignbyte(w[u].y, w[u].x, k + 1) : w[u].y;  // bytes q+k+1, q+k+2 in bits 0..15 (the shift is two bits wide)
-					if (q + k < npos) atomicAdd(&offs[(((b12 & 255u) << 5) ^ ((b12 >> 8) & 255u)) & 255u], 1u);
-				}
-			}
-		}
-	} else if (tid < NB) offs[tid] = a.sort_hist[(size_t)s * 128 + tid];
+	// digit histogram of this pass: counted by dfl_run_len_kernel, which reads the input in position order with the whole chip
+	// (here one workgroup per slice would wait for its loads, and pass A paid an LDS atomic per element for pass B's histogram)
+	if (tid < NB) offs[tid] = a.sort_hist[(size_t)s * 384 + (FIRST ? 0 : 256) + tid];
 	__syncthreads();
 	if (wave == 0) {  // exclusive scan of up to 256 bins: 4 per lane
 		uint32_t v[4], sum = 0;
@@ -255,7 +234,6 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 			if (valid) {
 				before = wcnt[wave][d];  // equal digits of this wave's earlier rounds
 				if (rank == 0) wcnt[wave][d] = before + (uint32_t)__popcll(same);
-				if (FIRST) atomicAdd(&next_hist[(h[e] & 0x7FFFu) >> 8], 1u);
 			}
 			rk[e] = before + rank;
 		}
@@ -280,10 +258,6 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 				rec_dst[dst] = (uint64_t)p[e] | ((uint64_t)h[e] << 32);
 			}
 		}
-	}
-	if (FIRST) {
-		__syncthreads();
-		if (tid < 128) a.sort_hist[(size_t)s * 128 + tid] = next_hist[tid];
 	}
 }
 
@@ -326,6 +300,9 @@ constexpr int RUNLEN_OUT = 2048 - 264;
 __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 {
 	__shared__ uint32_t wtot[4];  // per wave: has_change << 31 | distance from the wave's first position to its first change
+	__shared__ uint32_t hist[384];  // digits of the sort: hash & 255 of every string of this workgroup's positions, then hash >> 8
+	for (int t = threadIdx.x; t < 384; t += 256) hist[t] = 0;
+	__syncthreads();
 	const int s = blockIdx.y;
 	const uint32_t L = a.in_sizes[s];
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
@@ -335,16 +312,41 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
 		const uint32_t c0 = c * RUNLEN_OUT;
 		const uint32_t g = c0 + threadIdx.x * 8;  // first of this lane's 8 positions
-		uint8_t b[10];                            // in[g-1 .. g+8]
-		if (g + 9 <= L && g >= 1) {
+		uint8_t b[11];                            // in[g-1 .. g+9]
+		if (g + 10 <= L && g >= 1) {
 			uint64_t w;
 			__builtin_memcpy(&w, in + g, 8);
 #pragma unroll
 			for (int k = 0; k < 8; k++) b[k + 1] = (uint8_t)(w >> (8 * k));
-			b[0] = in[g - 1]; b[9] = in[g + 8];
+			b[0] = in[g - 1];
+			uint16_t w2; __builtin_memcpy(&w2, in + g + 8, 2);
+			b[9] = (uint8_t)w2; b[10] = (uint8_t)(w2 >> 8);
 		} else {
 #pragma unroll
-			for (int k = 0; k < 10; k++) { const int64_t y = (int64_t)g - 1 + k; b[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
+			for (int k = 0; k < 11; k++) { const int64_t y = (int64_t)g - 1 + k; b[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
+		}
+		// the sort's digit histograms (UPDATE_HASH of the three bytes from every published position that starts a string).
+		// A quarter of a CT payload is runs of one byte: a lane whose strings all hash alike adds them in one go, and so does
+		// a wave (every lane adding 1 to the same two counters made this kernel 0.31 instead of 0.09 ms)
+		{
+			uint32_t hk[8], cnt = 0, h0 = 0;
+			bool same = true;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const bool v = threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT && g + k + 2 < L;
+				hk[k] = v ? (((uint32_t)b[k + 1] << 10) ^ ((uint32_t)b[k + 2] << 5) ^ (uint32_t)b[k + 3]) & 0x7FFFu : 0xFFFFFFFFu;
+				if (v) { if (!cnt) h0 = hk[k]; else same &= hk[k] == h0; cnt++; }
+			}
+			const bool wave_same = __all(same && cnt == 8 && h0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)h0));
+			if (wave_same) {
+				if (lane == 0) { atomicAdd(&hist[h0 & 255u], 512u); atomicAdd(&hist[256u + (h0 >> 8)], 512u); }
+			} else if (same) {
+				if (cnt) { atomicAdd(&hist[h0 & 255u], cnt); atomicAdd(&hist[256u + (h0 >> 8)], cnt); }
+			} else {
+#pragma unroll
+				for (int k = 0; k < 8; k++)
+					if (hk[k] != 0xFFFFFFFFu) { atomicAdd(&hist[hk[k] & 255u], 1u); atomicAdd(&hist[256u + (hk[k] >> 8)], 1u); }
+			}
 		}
 		uint32_t chg = 0;  // bit k: the run containing position g+k ends at g+k
 #pragma unroll
@@ -385,6 +387,9 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 			}
 		}
 	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < 384; t += 256)
+		if (hist[t]) atomicAdd(&a.sort_hist[(size_t)s * 384 + t], hist[t]);
 }
 
 // length of the common prefix of x and y, continuing from len, capped at cap; 8 bytes per step
@@ -1924,6 +1929,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 {
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(a.sort_hist, 0, (size_t)n * 384 * 4, st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	(void)sort_temp; (void)sort_temp_bytes;
