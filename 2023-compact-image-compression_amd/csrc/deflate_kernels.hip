@@ -652,77 +652,131 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 // followed by the same byte c = in[p+r], can be longer.  So instead of 4096 chain steps the lane scans
 // the (much shorter) list of run ends backwards.  Chain-length limits translate into position limits
 // through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
-__global__ void __launch_bounds__(1024) dfl_run_ends_kernel(DeflateArgs a)
+// Ordered lists of the ends AND starts of runs of >= 3 equal bytes, per slice.  A workgroup takes one chunk of 8192 bytes (8 per
+// lane): dfl_run_count_kernel counts the entries of every chunk, dfl_run_lists_kernel sums the counts of the chunks before its
+// own and writes its entries at that offset (a workgroup prefix sum over the flag counts places them, so both lists come out in
+// position order), dfl_run_info_kernel pairs the k-th start with the k-th end (run length without scanning).  Until round 3
+// this was one workgroup per slice walking its 34 chunks in a row (0.18 ms per batch, nearly all of it waiting).
+// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
+// Chunk counts: two words per chunk at the start of the slice's heavy-list area, which nothing uses before the match kernel.
+constexpr uint32_t RUN_CHUNK = 8192;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
-	// one workgroup per slice: ordered lists of the ends AND starts of runs of >= 3 equal bytes.  The slice is read
-	// in coalesced chunks of 8192 bytes (8 per lane); per chunk a workgroup prefix sum over the flag counts places
-	// the entries, so both lists come out in position order.  The k-th start belongs to the k-th end, which gives
-	// the run length without scanning.
-	// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
-	__shared__ uint32_t wsum_e[2][16], wsum_s[2][16];
-	const int s = blockIdx.x;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+	return v;
+}
+
+// bit k = bytes k and k+1... of two words differ nowhere: equal-byte mask of d = a ^ b, four bytes at a time
+__device__ __forceinline__ uint32_t eq4(uint32_t d)
+{
+	const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;  // bit 7 of every byte that is not zero
+	const uint32_t eq = (~nz >> 7) & 0x01010101u;
+	return ((eq * 0x204081u) >> 21) & 15u;  // bits 0, 8, 16, 24 -> bits 0..3 (no two partial products meet)
+}
+
+// flags of the lane's 8 positions x0 .. x0+7 (x0 a multiple of 8): bit k of me = a run of >= 3 ends before x0+k, of ms = one
+// starts at x0+k.  Both follow from EQ, bit i = (in[x0-3+i] == in[x0-2+i]) for the pairs inside [0, L): twelve byte compares
+// done four at a time (the byte-by-byte version, ~200 instructions per lane, was what these kernels spent their time on;
+// checked against it on the host for 1.6 M random windows).
+__device__ __forceinline__ void run_flags(const uint8_t *in, uint32_t L, size_t in_stride, uint32_t x0, uint32_t &me, uint32_t &ms)
+{
+	// bytes in[x .. x+7] from a clamped address (no branch around the loads: the three words of a lane are in flight together);
+	// what lies outside [0, L) is masked out of EQ below
+	const int64_t xmax = (int64_t)in_stride - 8;
+	auto load8 = [&](int64_t x) -> uint64_t { return *reinterpret_cast<const uint64_t *>(in + min(max(x, (int64_t)0), xmax)); };
+	const uint64_t wp = load8((int64_t)x0 - 8), wc = load8((int64_t)x0), wn = load8((int64_t)x0 + 8);
+	me = 0; ms = 0;
+	if (x0 >= L) return;
+	const uint32_t w0 = (uint32_t)((wp >> 40) | (wc << 24)), s0 = (uint32_t)((wp >> 48) | (wc << 16));  // bytes x0-3.., x0-2..
+	const uint32_t w1 = (uint32_t)(wc >> 8), s1 = (uint32_t)(wc >> 16);                                  // bytes x0+1.., x0+2..
+	const uint32_t w2 = (uint32_t)((wc >> 40) | (wn << 24)), s2 = (uint32_t)((wc >> 48) | (wn << 16));  // bytes x0+5.., x0+6..
+	uint32_t EQ = eq4(w0 ^ s0) | (eq4(w1 ^ s1) << 4) | (eq4(w2 ^ s2) << 8);
+	const uint32_t lo = x0 >= 3 ? 0u : 3u - x0;              // first pair inside the input
+	const uint32_t hi = min(12u, L + 2u - x0);               // pairs i < L + 2 - x0 end inside it
+	EQ &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+	const uint32_t pv = L - x0 >= 8 ? 0xFFu : (1u << (L - x0)) - 1u;  // positions below L
+	me = EQ & (EQ >> 1) & ~(EQ >> 2) & pv;
+	ms = (EQ >> 3) & (EQ >> 4) & ~(EQ >> 2) & 0xFFu;
+}
+
+__global__ void __launch_bounds__(1024) dfl_run_count_kernel(DeflateArgs a)
+{
+	__shared__ uint32_t wsum_e[16], wsum_s[16];
+	const int s = blockIdx.y;
 	const uint32_t L = a.in_sizes[s];
+	const uint32_t c = blockIdx.x;
+	if (c * RUN_CHUNK >= L) return;
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t me, ms;
+	run_flags(in, L, a.in_stride, c * RUN_CHUNK + (uint32_t)tid * 8, me, ms);
+	const uint32_t ne = wave_sum((uint32_t)__popc(me)), ns = wave_sum((uint32_t)__popc(ms));
+	if (lane == 0) { wsum_e[wave] = ne; wsum_s[wave] = ns; }
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t te = 0, ts = 0;
+		for (int w = 0; w < 16; w++) { te += wsum_e[w]; ts += wsum_s[w]; }
+		uint32_t *cnt = a.heavy_list + (size_t)s * a.in_stride;
+		cnt[2 * c] = te; cnt[2 * c + 1] = ts;
+	}
+}
+
+__global__ void __launch_bounds__(1024) dfl_run_lists_kernel(DeflateArgs a)
+{
+	__shared__ uint32_t wsum_e[16], wsum_s[16], base_es[2];
+	const int s = blockIdx.y;
+	const uint32_t L = a.in_sizes[s];
+	const uint32_t c = blockIdx.x;
+	if (c * RUN_CHUNK >= L) return;
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
 	uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
 	uint32_t *rs = re + (a.in_stride >> 2);
-	uint32_t *rl = re + (a.in_stride >> 1);
+	const uint32_t *cnt = a.heavy_list + (size_t)s * a.in_stride;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	// bytes in[x .. x+7] for x a multiple of 8, zero outside [0, L): one aligned load from a clamped address, masked afterwards
-	// (no branch around the load: the three words of a lane are in flight together, and the next chunk's are requested before
-	// this chunk's lists are written)
-	const int64_t xmax = (int64_t)a.in_stride - 8;
-	auto load8 = [&](int64_t x) -> uint64_t { return *reinterpret_cast<const uint64_t *>(in + min(max(x, (int64_t)0), xmax)); };
-	auto clip8 = [&](uint64_t w, int64_t x) -> uint64_t {
-		if (x < 0 || x >= (int64_t)L) return 0ull;
-		return x + 8 > (int64_t)L ? w & ((1ull << (8 * ((int64_t)L - x))) - 1ull) : w;
-	};
-	uint32_t base_e = 0, base_s = 0;
-	int par = 0;
-	uint64_t np = load8((int64_t)tid * 8 - 8), nc = load8((int64_t)tid * 8), nn = load8((int64_t)tid * 8 + 8);
-	for (uint32_t c0 = 0; c0 < L; c0 += 8192, par ^= 1) {
-		const uint32_t x0 = c0 + (uint32_t)tid * 8;
-		uint32_t me = 0, ms = 0;
-		const uint64_t wp = clip8(np, (int64_t)x0 - 8), wc = clip8(nc, x0), wn = clip8(nn, (int64_t)x0 + 8);
-		np = load8((int64_t)x0 + 8192 - 8); nc = load8((int64_t)x0 + 8192); nn = load8((int64_t)x0 + 8192 + 8);
-		if (x0 < L) {
-			auto bt = [&](int i) -> uint32_t {  // in[x0 + i], i in [-3, 9]
-				return i < 0 ? (uint32_t)(wp >> (8 * (i + 8))) & 0xFFu : i < 8 ? (uint32_t)(wc >> (8 * i)) & 0xFFu : (uint32_t)(wn >> (8 * (i - 8))) & 0xFFu;
-			};
-#pragma unroll
-			for (int k = 0; k < 8; k++) {
-				const uint32_t x = x0 + k;
-				const bool e = x >= 3 && x < L && bt(k - 1) == bt(k - 2) && bt(k - 2) == bt(k - 3) && bt(k) != bt(k - 1);
-				const bool st = x + 2 < L && bt(k + 1) == bt(k) && bt(k + 2) == bt(k) && (x == 0 || bt(k - 1) != bt(k));
-				me |= (uint32_t)e << k; ms |= (uint32_t)st << k;
-			}
-		}
-		const uint32_t ne = (uint32_t)__popc(me), ns = (uint32_t)__popc(ms);
-		uint32_t inc_e = ne, inc_s = ns;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t oe = __shfl_up(inc_e, d, 64), os = __shfl_up(inc_s, d, 64);
-			if (lane >= d) { inc_e += oe; inc_s += os; }
-		}
-		if (lane == 63) { wsum_e[par][wave] = inc_e; wsum_s[par][wave] = inc_s; }
-		__syncthreads();  // (double-buffered sums: one barrier per chunk)
-		uint32_t ie = base_e + inc_e - ne, is = base_s + inc_s - ns;
-		for (int w2 = 0; w2 < 16; w2++) {
-			const uint32_t te = wsum_e[par][w2], ts = wsum_s[par][w2];
-			if (w2 < wave) { ie += te; is += ts; }
-			base_e += te; base_s += ts;
-		}
-		asm volatile("" : "+v"(np), "+v"(nc), "+v"(nn) :: "memory");  // taken before the stores below: see dfl_sort_pass_kernel
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			if ((me >> k) & 1u) re[ie++] = x0 + k;
-			if ((ms >> k) & 1u) rs[is++] = x0 + k;
-		}
+	const uint32_t x0 = c * RUN_CHUNK + (uint32_t)tid * 8;
+	// entries of the chunks before this one (wave 0 sums them while the others compute their flags)
+	if (wave == 0) {
+		uint32_t be = 0, bs = 0;
+		for (uint32_t q = lane; q < c; q += 64) { be += cnt[2 * q]; bs += cnt[2 * q + 1]; }
+		be = wave_sum(be); bs = wave_sum(bs);
+		if (lane == 0) { base_es[0] = be; base_es[1] = bs; }
 	}
-	const uint32_t nre = base_e;
-	if (tid == 0) a.run_end_count[s] = nre;
-	__threadfence();
+	uint32_t me, ms;
+	run_flags(in, L, a.in_stride, x0, me, ms);
+	const uint32_t ne = (uint32_t)__popc(me), ns = (uint32_t)__popc(ms);
+	uint32_t inc_e = ne, inc_s = ns;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t oe = __shfl_up(inc_e, d, 64), os = __shfl_up(inc_s, d, 64);
+		if (lane >= d) { inc_e += oe; inc_s += os; }
+	}
+	if (lane == 63) { wsum_e[wave] = inc_e; wsum_s[wave] = inc_s; }
 	__syncthreads();
-	for (uint32_t t = tid; t < nre; t += 1024) {
+	uint32_t ie = base_es[0] + inc_e - ne, is = base_es[1] + inc_s - ns, tot_e = base_es[0];
+	for (int w2 = 0; w2 < 16; w2++) {
+		const uint32_t te = wsum_e[w2], ts = wsum_s[w2];
+		if (w2 < wave) { ie += te; is += ts; }
+		tot_e += te;
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		if ((me >> k) & 1u) re[ie++] = x0 + k;
+		if ((ms >> k) & 1u) rs[is++] = x0 + k;
+	}
+	if (tid == 0 && (c + 1) * RUN_CHUNK >= L) a.run_end_count[s] = tot_e;  // the slice's last chunk
+}
+
+__global__ void __launch_bounds__(256) dfl_run_info_kernel(DeflateArgs a)
+{
+	const int s = blockIdx.y;
+	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
+	const uint32_t *rs = re + (a.in_stride >> 2);
+	uint32_t *rl = a.run_ends + (size_t)s * a.in_stride + (a.in_stride >> 1);
+	const uint32_t nre = a.run_end_count[s];
+	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nre; t += gridDim.x * blockDim.x) {
 		const uint32_t x = re[t], len = x - rs[t];
 		rl[t] = (len < 511u ? len : 511u) | ((uint32_t)in[x - 1] << 16);
 	}
@@ -1124,12 +1178,6 @@ __device__ __forceinline__ uint32_t sift_root(TreeScratch &S, uint32_t v, int hl
 	return rootv;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-	return v;
-}
 
 // build_tree + gen_bitlen + gen_codes (trees.c:486-700) in five phases.  The heap replay and the overflow repair are
 // serial (one lane per block: dfl_tree_kernel runs them for several blocks at once, one block per lane); the phases
@@ -1867,7 +1915,7 @@ __global__ void dfl_offsets2_kernel(DeflateArgs a, int n)
 __global__ void dfl_offsets_kernel(DeflateArgs a, int n)
 {
 	if (blockIdx.x == 0) {
-		for (int s = threadIdx.x; s < n; s += blockDim.x) { a.postloop_lit[s] = 0; a.heavy_count[s] = 0; a.deep_count[s] = 0; }
+		for (int s = threadIdx.x; s < n; s += blockDim.x) { a.postloop_lit[s] = 0; a.heavy_count[s] = 0; a.deep_count[s] = 0; a.run_end_count[s] = 0; }  // (run_end_count: an empty slice has no chunk that would write it)
 		if (threadIdx.x == 0) *a.gen = *a.gen % GEN_MAX + 1u;  // tag of this pass's match records (see MatchRec)
 	}
 }
@@ -1936,7 +1984,10 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);       // run-length words (pass A puts them into the records, the parse reads them)
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> rec_in by hash & 255
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> rec_out by hash >> 8
-	hipLaunchKernelGGL(dfl_run_ends_kernel, dim3(n), dim3(1024), 0, st, a);         // writes over rec_in, dead after the sort
+	const int nrc = (int)((a.in_stride + RUN_CHUNK - 1) / RUN_CHUNK);
+	hipLaunchKernelGGL(dfl_run_count_kernel, dim3(nrc, n), dim3(1024), 0, st, a);
+	hipLaunchKernelGGL(dfl_run_lists_kernel, dim3(nrc, n), dim3(1024), 0, st, a);   // writes over rec_in, dead after the sort
+	hipLaunchKernelGGL(dfl_run_info_kernel, dim3(8, n), dim3(256), 0, st, a);
 	// wide records: one 256-lane block per 256 positions (more of them in flight hide the scattered accesses better than grid-stride
 	// loops); compact records: the kernel is bound by its instructions, and 256 blocks per slice with four turns each measured best
 	// (486 us against 499 / 510 with 128 / 512, profiles/r03_match_grid.log)
