@@ -166,7 +166,7 @@ def pmc_traffic():
             sha = hashlib.sha1(f.read()).hexdigest()
         if pmc.get("source_sha1") == sha:
             return pmc["traffic_bytes_per_launch"], os.path.relpath(PMC_JSON, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, same launch shape)"
-        return None, "stale: " + os.path.relpath(PMC_JSON, ROOT) + " was collected with another encode_pipe.hip"
+        return None, "stale: " + os.path.relpath(PMC_JSON, ROOT) + " was collected with another encode_stream.hip"
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="finish decode of step k before encoding step k+1")
     ap.add_argument("--no-slot-comparison", action="store_true",
                     help="skip the short run with the other --encode-slots setting after the timed region (use under a tracer)")
+    ap.add_argument("--no-pipeline-scheduling", action="store_true",
+                    help="library options decode_yields = 0 and queue_ahead = 0: decode kernels start at once, an encode call keeps its "
+                         "slot until the host has the sizes (rounds 1-2; for the A/B in profiles/)")
     ap.add_argument("--encode-slots", type=int, default=1, choices=(1, 2),
                     help="encode batches on the device at a time (library option encode_slots; 2 is worth -8 ... +8 %% end to end depending on "
                          "the box, but then every kernel's duration includes another batch's "
@@ -235,6 +238,9 @@ def main():
         zthreads = int(os.environ["CCT_HOST_THREADS"])
     _ffi.check(L.cct_set_option(b"zlib_threads", zthreads))
     _ffi.check(L.cct_set_option(b"encode_slots", args.encode_slots))
+    if args.no_pipeline_scheduling:
+        _ffi.check(L.cct_set_option(b"decode_yields", 0))
+        _ffi.check(L.cct_set_option(b"queue_ahead", 0))
     for env, key in (("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
                      ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path"),
                      ("CCT_ENCODE_SLOTS", b"encode_slots")):
@@ -466,7 +472,7 @@ def main():
                        "phantom": args.phantom, "max_pixel_value": int(max(int(b.max()) for b in batches)),
                        "slices_per_gpu": n, "width": W, "height": H, "block_size": bs,
                        "flags": "fractal+segmentation+deflate(level 9)", "sharding": f"per-slice, {world} GPU(s)",
-                       "encode_slots": args.encode_slots},
+                       "encode_slots": args.encode_slots, "pipeline_scheduling": not args.no_pipeline_scheduling},
             "roofline": main_roof,
             "hbm_read_roofline_end_to_end": {  # north_star: the whole job against the HBM-read roofline (2 B per pixel per step)
                 "achieved": round(2.0 * npx * world / (ms_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",

@@ -38,7 +38,7 @@ def per_kernel(path, counter):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     keep = ["bench.json", "bench_under_rocprof.json", "bench_kernel_stats.csv", "bench_two_slots.json",
-            "bench_two_slots_under_rocprof.json", "bench_two_slots_kernel_stats.csv", "bench_no_overlap.json",
+            "bench_two_slots_under_rocprof.json", "bench_two_slots_kernel_stats.csv", "bench_no_overlap.json", "bench_no_pipeline_scheduling.json",
             "bench_config4.json", "bench_config5.json", "pmc_FETCH_SIZE_counter_collection.csv",
             "pmc_WRITE_SIZE_counter_collection.csv", "pmc_sq_counter_collection.csv", "prof_encode.log", "prof_codec.log", "codec_serial_kernel_stats.csv",
             "pmc_codec_FETCH_SIZE_counter_collection.csv", "pmc_codec_WRITE_SIZE_counter_collection.csv", "pmc_codec_sq_counter_collection.csv",

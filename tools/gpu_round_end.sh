@@ -18,6 +18,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 find $O/prof1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_two_slots_kernel_stats.csv
 rm -rf $O/prof1
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-overlap > $O/bench_no_overlap.json 2> $O/bench_no_overlap.err
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-slot-comparison --no-pipeline-scheduling > $O/bench_no_pipeline_scheduling.json 2> $O/bench_no_pipeline_scheduling.err
 echo "two slots / no overlap done"
 timeout -k 10 600 python bench.py --config 4 --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err
 timeout -k 10 300 python bench.py --config 5 --no-cpu-baseline > $O/bench_config5.json 2> $O/bench_config5.err
@@ -51,6 +52,6 @@ CCT_STREAM_STAMPS=1 timeout -k 10 200 python tools/prof_encode.py --paths 1 --re
 echo "pmc done"
 python -c "
 import json
-for f in ('bench','bench_two_slots','bench_no_overlap','bench_config4','bench_config5'):
+for f in ('bench','bench_two_slots','bench_no_overlap','bench_no_pipeline_scheduling','bench_config4','bench_config5'):
     d=json.load(open('$O/'+f+'.json')); print(f, d['value'], d['ms_per_step'], d['roofline']['avg_ms'], d['roofline']['frac'])
 "
