@@ -1164,13 +1164,25 @@ __device__ __forceinline__ uint32_t sift_root(TreeScratch &S, uint32_t v, int hl
 	const uint32_t rootv = moving ? e : v;
 	S.heap[1] = rootv;
 	uint32_t k = 2u + right;
-	for (int l = 1; l < levels; l++) {
+	// levels 1 .. levels-2: k lies above the last full level (depth < levels - 1), so both children exist (2k + 1 < 2^levels <= hl)
+	// and nothing needs a bound -- a third fewer instructions per level than the general step below, and these are most levels
+	for (int l = 1; l < levels - 1; l++) {
+		const uint32_t j = k << 1;
+		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[j]);
+		right = pr.y <= (pr.x | 1023u) ? 1u : 0u;
+		e = right ? pr.y : pr.x;
+		const uint32_t go = (moving && v > (e | 1023u)) ? 1u : 0u;
+		S.heap[moving ? k : 0u] = go ? e : v;  // the hole at k receives the smaller child, or v (which then stays there)
+		k = go ? j + right : k;
+		moving = go;
+	}
+	if (levels >= 2) {  // (uniform) the last level: children may lie past the end of the heap
 		const uint32_t j = k << 1;
 		const uint2 pr = *reinterpret_cast<const uint2 *>(&S.heap[min(j, (uint32_t)(HEAP_SIZE - 1))]);
 		right = (j < (uint32_t)hl && pr.y <= (pr.x | 1023u)) ? 1u : 0u;
 		e = right ? pr.y : pr.x;
 		const uint32_t go = (moving && j <= (uint32_t)hl && v > (e | 1023u)) ? 1u : 0u;
-		S.heap[moving ? k : 0u] = go ? e : v;  // the hole at k receives the smaller child, or v (which then stays there)
+		S.heap[moving ? k : 0u] = go ? e : v;
 		k = go ? j + right : k;
 		moving = go;
 	}
@@ -1546,19 +1558,29 @@ __global__ void __launch_bounds__(64) dfl_tree_kernel(DeflateArgs a)
 		for (int i = lane; i < L_CODES; i += 64) hl[i] = 0;
 		if (lane < D_CODES) hd[lane] = 0;
 		__syncthreads();
-		for (uint32_t i0 = 0; i0 < nsym; i0 += 64 * 16) {  // sixteen loads in flight: one wave per block, nothing else hides HBM latency
-			uint32_t v[16];
+		// sixteen loads in flight (one wave per block, nothing else hides HBM latency), and the next sixteen requested before
+		// these are counted: the index is clamped instead of tested so that the loads carry no branch
+		{
+			const uint32_t lasts = nsym ? nsym - 1 : 0;
+			uint32_t nv[16];
 #pragma unroll
-			for (int k = 0; k < 16; k++) { const uint32_t i = i0 + (uint32_t)(k * 64 + lane); v[k] = i < nsym ? sym[i] : 0xFFFFFFFFu; }
+			for (int k = 0; k < 16; k++) nv[k] = sym[min((uint32_t)(k * 64 + lane), lasts)];
+			for (uint32_t i0 = 0; i0 < nsym; i0 += 64 * 16) {
+				uint32_t v[16];
 #pragma unroll
-			for (int k = 0; k < 16; k++) {
-				if (v[k] == 0xFFFFFFFFu) continue;  // (a symbol never looks like this: length codes are <= 255)
-				const uint32_t dist = v[k] >> 16, lc = v[k] & 0xFFu;
-				if (dist == 0) atomicAdd(&hl[lc], 1u);
-				else {
-					const uint32_t d1 = dist - 1;
-					atomicAdd(&hl[length_code[lc] + 256 + 1], 1u);
-					atomicAdd(&hd[d1 < 256 ? dist_code[d1] : dist_code[256 + (d1 >> 7)]], 1u);
+				for (int k = 0; k < 16; k++) v[k] = nv[k];
+#pragma unroll
+				for (int k = 0; k < 16; k++) nv[k] = sym[min(i0 + 1024u + (uint32_t)(k * 64 + lane), lasts)];
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					if (i0 + (uint32_t)(k * 64 + lane) >= nsym) continue;
+					const uint32_t dist = v[k] >> 16, lc = v[k] & 0xFFu;
+					if (dist == 0) atomicAdd(&hl[lc], 1u);
+					else {
+						const uint32_t d1 = dist - 1;
+						atomicAdd(&hl[length_code[lc] + 256 + 1], 1u);
+						atomicAdd(&hd[d1 < 256 ? dist_code[d1] : dist_code[256 + (d1 >> 7)]], 1u);
+					}
 				}
 			}
 		}
