@@ -814,3 +814,69 @@ def test_concurrent_encodes_and_decodes_use_their_slots(hip):
     finally:
         _ffi.check(L.cct_set_option(b"encode_slots", 1))
         _ffi.check(L.cct_set_option(b"decode_slots", 2))
+
+
+@pytest.mark.parametrize("scheduling", [1, 0], ids=["gate+queue_ahead", "launch_at_once"])
+def test_pipelined_packed_calls_with_and_without_the_scheduling_measures(hip, scheduling):
+    """The bench's pipeline in small: two threads encode into page-locked archives (cct_encode_batch_packed), one decodes the
+    archive of the step before on its own stream.  With the decode gate and the queue-ahead handover and without
+    them, every archive equals the serial one and every raster its input; a decode issued while the LAST encode runs
+    (nothing follows: the gate gives up after its grace time) returns as well."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from cct_hip import _ffi
+    from cct_hip.batch import PinnedArray, DeviceBuffer
+    L = _ffi.lib()
+    cfg = hip.default_config()
+    flags, bs, eof, magic, ch, bpc = hip.codec_params(cfg, np.uint16)
+    n, W = 32, 256
+    batches = [np.stack([gi.ct_phantom(100 * k + i, W) for i in range(n)]) for k in range(3)]
+    serial = [b"".join(hip.encode_batch(b, cfg)) for b in batches]
+    cap = L.cct_file_bound(W, W, bs) * n
+    d_imgs = [DeviceBuffer.from_numpy(b) for b in batches]
+    NSET = 3
+    pins = [PinnedArray(cap) for _ in range(NSET)]
+    arch = [p.array for p in pins]
+    offs = [np.zeros(n + 1, dtype=np.uint64) for _ in range(NSET)]
+    sizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    status = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    psizes = [np.zeros(n, dtype=np.uint32) for _ in range(NSET)]
+    d_back = [DeviceBuffer(n * W * W * 2) for _ in range(NSET)]
+
+    def enc(i):
+        k = i % NSET
+        _ffi.check(L.cct_encode_batch_packed(d_imgs[i % 3].ptr, 1, n, W, W, bs, flags, eof, magic, ch, bpc, arch[k].ctypes.data, cap,
+                                             offs[k].ctypes.data, sizes[k].ctypes.data, status[k].ctypes.data,
+                                             psizes[k].ctypes.data, None))
+        total = int(offs[k][n])
+        assert arch[k][:total].tobytes() == serial[i % 3], f"step {i}"
+        return k
+
+    def dec(fut, i):
+        k = fut.result()
+        st = np.zeros(n, dtype=np.uint32)
+        _ffi.check(L.cct_decode_batch(arch[k].ctypes.data, offs[k].ctypes.data, n, bs, magic, d_back[k].ptr, 1, n * W * W, st.ctypes.data))
+        assert np.array_equal(d_back[k].download(np.uint16, n * W * W).reshape(n, W, W), batches[i % 3]), f"step {i}"
+
+    try:
+        _ffi.check(L.cct_set_option(b"decode_yields", scheduling))
+        _ffi.check(L.cct_set_option(b"queue_ahead", scheduling))
+        with ThreadPoolExecutor(2) as pe, ThreadPoolExecutor(1) as pd:
+            decs, prev = [], None
+            for i in range(12):
+                while len(decs) >= NSET:
+                    decs.pop(0).result()
+                e = pe.submit(enc, i)
+                decs.append(pd.submit(dec, e, i))
+                if prev is not None:
+                    prev.result()
+                prev = e
+            for d in decs:
+                d.result()
+    finally:
+        _ffi.check(L.cct_set_option(b"decode_yields", 1))
+        _ffi.check(L.cct_set_option(b"queue_ahead", 1))
+        for b in d_imgs + d_back:
+            b.free()
+        for p_ in pins:
+            p_.free()
