@@ -90,7 +90,7 @@ struct EncSlot {
 	DevBuf h_small[2];  // pinned landing place of a call's sizes / status / statistics (a copy to pageable memory blocks the host until it has happened)
 	// device DEFLATE workspaces
 	DevBuf z_vals_in, z_vals_out, z_mr, z_rec, z_exitp, z_exitc, z_sym, z_bentry, z_bsym,
-	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs, z_gen;
+	    z_small, z_bend, z_meta, z_tables, z_sorttmp, z_out, z_outsizes, z_in, z_insizes, z_packed, z_packoffs, z_gen, z_runs;
 	// match records are valid by tag (deflate_kernels.hip MatchRec): the device counter z_gen has run z_gen_passes times since
 	// the buffer z_mr_cleared (z_mr at that time) was last zeroed together with it
 	const void *z_mr_cleared = nullptr;
@@ -101,6 +101,8 @@ struct EncSlot {
 	hipEvent_t ev_k0s[2] = {nullptr, nullptr}, ev_k1s[2] = {nullptr, nullptr};  // around the transform+pack stage
 	hipEvent_t ev_z0s[2] = {nullptr, nullptr}, ev_z1s[2] = {nullptr, nullptr};  // around the device DEFLATE pass
 	hipEvent_t ev_small[2] = {nullptr, nullptr};                                // sizes and status have reached the host
+	hipStream_t stream_side = nullptr;                                          // side branch of the DEFLATE pass (launch_deflate)
+	hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr};
 	unsigned call_parity = 0;
 	DevBuf *all_bufs[48];
 	int n_bufs = 0;
@@ -109,7 +111,7 @@ struct EncSlot {
 		DevBuf *b[] = {&e_role, &e_lidx, &e_lmask, &e_lcur, &e_images, &e_payload, &e_sizes, &e_status, &e_stats, &e_toff, &e_pairrec,
 		               &e_spill, &e_tflag, &e_hand, &h_stage, &z_vals_in, &z_vals_out, &z_mr, &z_rec, &z_exitp, &z_exitc,
 		               &z_sym, &z_bentry, &z_bsym, &z_small, &z_bend, &z_meta, &z_tables, &z_sorttmp, &z_out, &z_outsizes, &z_in,
-		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1], &z_gen, &h_small[0], &h_small[1]};
+		               &z_insizes, &z_packed, &z_packoffs, &z_packed2[0], &z_packed2[1], &z_gen, &z_runs, &h_small[0], &h_small[1]};
 		for (DevBuf *p : b) all_bufs[n_bufs++] = p;
 		h_stage.pinned_host = true;
 		h_small[0].pinned_host = h_small[1].pinned_host = true;
@@ -149,6 +151,7 @@ struct Context {
 	int device = -1;
 	hipStream_t stream = nullptr;  // main stream: plumbing calls, cct_encode_payload_dev, encode slot 0
 	int use_graph = 1;
+	int deflate_fork = 1;   // independent kernels of the DEFLATE pass on a side branch (launch_deflate)
 	int queue_ahead = 1;    // an encode call hands its slot on before it waits for the sizes (encode_batch_impl)
 	int decode_yields = 1;  // decode kernels issued next to an encode wait for the next transform+pack stage to end (cct_decode_batch)
 	int compact_recs = 1;  // sort records that carry the first five string bytes (slices below 4 MiB; deflate_kernels.hip "Sort records")
@@ -279,6 +282,8 @@ int ensure_ctx(int device)
 			HIP_TRY(hipEventCreate(&E.ev_z1s[q]));
 			HIP_TRY(hipEventCreateWithFlags(&E.ev_small[q], hipEventDisableTiming));
 		}
+		HIP_TRY(hipStreamCreateWithFlags(&E.stream_side, hipStreamNonBlocking));
+		for (int q = 0; q < 4; q++) HIP_TRY(hipEventCreateWithFlags(&E.ev_fork[q], hipEventDisableTiming));
 	}
 	for (int k = 0; k < N_DEC_SLOTS; k++) {
 		DecSlot &D = g_dec[k];
@@ -817,13 +822,15 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	if ((rc = E.z_vals_in.ensure(EB * 8))) return rc;   // records between the two sort passes, then run_ends + run_len
 	if ((rc = E.z_vals_out.ensure(EB * 8))) return rc;  // sorted records
 	if ((rc = E.z_mr.ensure(EB * 8))) return rc;
+	if ((rc = E.z_runs.ensure(EB * 4))) return rc;
 	if ((rc = E.z_rec.ensure(EB * 4))) return rc;
 	if ((rc = E.z_sym.ensure(EB * 4))) return rc;
 	if ((rc = E.z_exitp.ensure(EB * 4))) return rc;
 	if ((rc = E.z_exitc.ensure(EB * 4))) return rc;
 	if ((rc = E.z_bentry.ensure(EB / 64 * 4))) return rc;
 	if ((rc = E.z_bsym.ensure(EB / 64 * 4))) return rc;
-	if ((rc = E.z_small.ensure((size_t)n * (9 + 384) * 4))) return rc;
+	const int run_chunks = (int)(in_stride / 1784 + 1);  // chunks of dfl_run_len_kernel (RUNLEN_OUT positions) per slice
+	if ((rc = E.z_small.ensure((size_t)n * (9 + 384 + 2 * (size_t)run_chunks) * 4))) return rc;
 	if ((rc = E.z_bend.ensure((size_t)n * max_blocks * 4))) return rc;
 	if ((rc = E.z_meta.ensure((size_t)n * max_blocks * sizeof(BlockMeta)))) return rc;
 	if ((rc = E.z_tables.ensure((size_t)n * max_blocks * sizeof(BlockTables)))) return rc;
@@ -840,6 +847,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	uint32_t *small = (uint32_t *)E.z_small.p;
 	a.seg_begin = small; a.seg_end = small + n; a.total_syms = small + 2 * n; a.postloop_lit = small + 3 * n;
 	a.n_blocks = small + 4 * n; a.adler = small + 5 * n; a.heavy_count = small + 6 * n; a.deep_count = small + 7 * n; a.run_end_count = small + 8 * n; a.sort_hist = small + 9 * n;
+	a.run_counts = small + (9 + 384) * (size_t)n; a.run_chunks = run_chunks;
 	// the tag of a pass must not meet a record of 16383 passes ago: clear records and counter well before it comes round (and
 	// whenever the buffer is new); a pass that failed on the way may have left the two counts a few apart, hence the margin
 	if ((rc = E.z_gen.ensure(256))) return rc;
@@ -851,7 +859,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	E.z_gen_passes++;
 	a.gen = (uint32_t *)E.z_gen.p;
 	a.mr = E.z_mr.p; a.heavy_list = (uint32_t *)E.z_rec.p; a.sym = (uint32_t *)E.z_sym.p;
-	a.run_ends = (uint32_t *)E.z_vals_in.p;  // the half-sorted records are dead after the sort: 4 EB for the run list
+	a.run_ends = (uint32_t *)E.z_runs.p;  // 4 EB of their own: the lists are built while the sort runs (launch_deflate)
 	a.run_len = (uint16_t *)E.z_sym.p;  // 2 EB, written before the sort and dead before the symbols are
 	a.rec32 = (uint32_t *)E.z_exitp.p; a.exit_pos = (uint32_t *)E.z_exitc.p; a.exit_cnt = (uint32_t *)E.z_rec.p;  // the heavy/deep queues are dead once dfl_rec_kernel runs
 	a.blk_entry = (uint32_t *)E.z_bentry.p; a.blk_symbase = (uint32_t *)E.z_bsym.p;
@@ -862,9 +870,10 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	memcpy(a.header13, header13, 13);
 	if (g_ctx.use_graph) {
 		// whole batch on the main stream, as a graph keyed by everything the launches depend on
-		std::vector<uint8_t> key(sizeof(DeflateArgs) + sizeof(int));
+		std::vector<uint8_t> key(sizeof(DeflateArgs) + 2 * sizeof(int));
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
 		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
+		memcpy(key.data() + sizeof(DeflateArgs) + sizeof(int), &g_ctx.deflate_fork, sizeof(int));
 		EncSlot::ZGraph *zg = nullptr;
 		for (auto &g : E.z_graphs) if (g.key == key) zg = &g;
 		if (!zg) {
@@ -878,7 +887,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 				}
 				EncSlot::ZGraph g;
 				HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
-				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream);
+				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, g_ctx.deflate_fork ? E.stream_side : nullptr, E.ev_fork);
 				hipError_t ce = hipStreamEndCapture(E.stream, &g.graph);
 				if (le != hipSuccess) { if (g.graph) (void)hipGraphDestroy(g.graph); return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le)); }
 				HIP_TRY(ce);
@@ -895,7 +904,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 		HIP_TRY(hipGraphLaunch(zg->exec, E.stream));
 		return CCT_OK;
 	}
-	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream));
+	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, g_ctx.deflate_fork ? E.stream_side : nullptr, E.ev_fork));
 	return CCT_OK;
 }
 
@@ -975,9 +984,11 @@ int cct_shutdown(void)
 		for (auto &g : E.p_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
 		for (int i = 0; i < E.n_bufs; i++) E.all_bufs[i]->release();
 		hipEvent_t evs[] = {E.ev_k0s[0], E.ev_k1s[0], E.ev_z0s[0], E.ev_z1s[0], E.ev_k0s[1], E.ev_k1s[1], E.ev_z0s[1], E.ev_z1s[1],
-		                    E.ev_small[0], E.ev_small[1], E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1]};
+		                    E.ev_small[0], E.ev_small[1], E.ev_pack[0], E.ev_pack[1], E.ev_copied[0], E.ev_copied[1],
+		                    E.ev_fork[0], E.ev_fork[1], E.ev_fork[2], E.ev_fork[3]};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 		if (E.stream_copy) (void)hipStreamDestroy(E.stream_copy);
+		if (E.stream_side) { (void)hipStreamSynchronize(E.stream_side); (void)hipStreamDestroy(E.stream_side); }
 		if (k > 0 && E.stream) (void)hipStreamDestroy(E.stream);
 	}
 	comm_release();
@@ -1884,6 +1895,7 @@ int cct_set_option(const char *key, int value)
 	if (!strcmp(key, "deflate_compact_records")) { g_ctx.compact_recs = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "decode_yields")) { g_ctx.decode_yields = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "queue_ahead")) { g_ctx.queue_ahead = value ? 1 : 0; return CCT_OK; }
+	if (!strcmp(key, "deflate_fork")) { g_ctx.deflate_fork = value ? 1 : 0; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { g_ctx.enc_slots = std::max(1, std::min(value, N_ENC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { g_ctx.dec_slots = std::max(1, std::min(value, N_DEC_SLOTS)); return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) {
@@ -1910,6 +1922,7 @@ int cct_get_option(const char *key, int *value)
 	if (!strcmp(key, "deflate_compact_records")) { *value = g_ctx.compact_recs; return CCT_OK; }
 	if (!strcmp(key, "decode_yields")) { *value = g_ctx.decode_yields; return CCT_OK; }
 	if (!strcmp(key, "queue_ahead")) { *value = g_ctx.queue_ahead; return CCT_OK; }
+	if (!strcmp(key, "deflate_fork")) { *value = g_ctx.deflate_fork; return CCT_OK; }
 	if (!strcmp(key, "encode_slots")) { *value = g_ctx.enc_slots; return CCT_OK; }
 	if (!strcmp(key, "decode_slots")) { *value = g_ctx.dec_slots; return CCT_OK; }
 	if (!strcmp(key, "inflate_lanes")) { *value = g_ctx.inflate_lanes; return CCT_OK; }

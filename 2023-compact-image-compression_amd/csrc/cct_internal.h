@@ -160,6 +160,7 @@ struct DeflateArgs {
 	void *mr;                                                        // n * in_stride * 8 bytes: match records, valid where they carry the tag *gen
 	uint32_t *gen;                                                   // device counter of the passes run on this mr buffer, 1 .. 16383 (deflate_kernels.hip MatchRec)
 	uint32_t *heavy_list, *sym, *run_ends;                           // n * in_stride each
+	uint32_t *run_counts; int run_chunks;                            // n * 2 * run_chunks right behind sort_hist: run ends / starts per chunk of 1784 positions (run_chunks = chunks per slice)
 	uint32_t *sort_hist;                                             // n * 384: per slice the histograms of hash & 255 and of hash >> 8 (dfl_run_len_kernel -> sort passes)
 	uint16_t *run_len;                                               // n * in_stride: equal bytes ahead (<= 258) | has_prev << 15
 	uint32_t *rec32, *exit_pos, *exit_cnt;                           // n * in_stride each
@@ -175,7 +176,8 @@ hipError_t deflate_init_tables();
 size_t deflate_sort_temp_bytes(size_t total, int n);
 hipError_t launch_pack(const uint8_t *src, size_t stride, const uint32_t *sizes, int n, uint64_t *offsets, uint8_t *dst,
                        int exact, hipStream_t st);
-hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st);
+hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st, hipStream_t side = nullptr,
+                          const hipEvent_t *fork_join_events = nullptr);  // side + four events (no timing): independent kernels side by side
 
 // ---- gate between the decode and the encode stream (sched_kernels.hip) ---------------------------
 hipError_t launch_gate_bump(uint32_t *word, hipStream_t st);

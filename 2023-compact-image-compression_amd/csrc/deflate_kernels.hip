@@ -101,6 +101,13 @@ __device__ __forceinline__ void lds_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+	return v;
+}
+
 template <bool FIRST>
 __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 {
@@ -386,6 +393,24 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 				for (int k = 0; k < 8; k++) if (g + k < L && threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT) rl[g + k] = out[k];
 			}
 		}
+		// entries this chunk contributes to the lists of run ends and run starts (dfl_run_lists_kernel): position p ends a run of
+		// >= 3 three bytes on (exactly three equal bytes from p, the fourth inside the input) and starts one when >= 3 equal bytes
+		// follow and the byte before differs
+		{
+			uint32_t ce = 0, cs = 0;  // wave totals (ballots: scalar popcounts instead of a shuffle reduction)
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const bool pub = threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT && g + k < L;
+				const uint32_t r = out[k] & 0x7FFFu;
+				ce += (uint32_t)__popcll(__ballot(pub && r == 3u && g + k + 3 < L));
+				cs += (uint32_t)__popcll(__ballot(pub && r >= 3u && !(g + k >= 1 && b[k] == b[k + 1])));
+			}
+			if (lane == 0 && (ce | cs)) {  // (counters zeroed with the sort histograms: no barrier, no store where there is no run)
+				uint32_t *cnt = a.run_counts + (size_t)s * 2 * a.run_chunks;
+				if (ce) atomicAdd(&cnt[2 * c], ce);
+				if (cs) atomicAdd(&cnt[2 * c + 1], cs);
+			}
+		}
 	}
 	__syncthreads();
 	for (int t = threadIdx.x; t < 384; t += 256)
@@ -652,99 +677,49 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 // followed by the same byte c = in[p+r], can be longer.  So instead of 4096 chain steps the lane scans
 // the (much shorter) list of run ends backwards.  Chain-length limits translate into position limits
 // through the sorted order: the first K chain entries are the sorted indices i-1 .. i-K.
-// Ordered lists of the ends AND starts of runs of >= 3 equal bytes, per slice.  A workgroup takes one chunk of 8192 bytes (8 per
-// lane): dfl_run_count_kernel counts the entries of every chunk, dfl_run_lists_kernel sums the counts of the chunks before its
-// own and writes its entries at that offset (a workgroup prefix sum over the flag counts places them, so both lists come out in
-// position order), dfl_run_info_kernel pairs the k-th start with the k-th end (run length without scanning).  Until round 3
-// this was one workgroup per slice walking its 34 chunks in a row (0.18 ms per batch, nearly all of it waiting).
-// Buffer (in_stride words, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
-// Chunk counts: two words per chunk at the start of the slice's heavy-list area, which nothing uses before the match kernel.
-constexpr uint32_t RUN_CHUNK = 8192;
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Ordered lists of the ends AND starts of runs of >= 3 equal bytes, per slice, from the run-length words: position p puts
+// p + 3 on the list of ends when exactly three equal bytes start at p and the fourth byte lies inside the input, and p on the
+// list of starts when >= 3 equal bytes start at p and the byte before differs.  dfl_run_len_kernel has counted the entries of
+// every chunk of RUNLEN_OUT positions; a workgroup sums the counts of the chunks before its own and writes its entries at that
+// offset (a workgroup prefix sum places them, so both lists come out in position order); dfl_run_info_kernel pairs the k-th
+// start with the k-th end (run length without scanning).  Until round 3 one workgroup per slice walked its 8192-byte
+// chunks in a row, computing the flags byte by byte (0.18 ms per batch).
+// Buffer (in_stride words of its own, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
+__global__ void __launch_bounds__(256) dfl_run_lists_kernel(DeflateArgs a)
 {
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-	return v;
-}
-
-// bit k = bytes k and k+1... of two words differ nowhere: equal-byte mask of d = a ^ b, four bytes at a time
-__device__ __forceinline__ uint32_t eq4(uint32_t d)
-{
-	const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;  // bit 7 of every byte that is not zero
-	const uint32_t eq = (~nz >> 7) & 0x01010101u;
-	return ((eq * 0x204081u) >> 21) & 15u;  // bits 0, 8, 16, 24 -> bits 0..3 (no two partial products meet)
-}
-
-// flags of the lane's 8 positions x0 .. x0+7 (x0 a multiple of 8): bit k of me = a run of >= 3 ends before x0+k, of ms = one
-// starts at x0+k.  Both follow from EQ, bit i = (in[x0-3+i] == in[x0-2+i]) for the pairs inside [0, L): twelve byte compares
-// done four at a time (the byte-by-byte version, ~200 instructions per lane, was what these kernels spent their time on;
-// checked against it on the host for 1.6 M random windows).
-__device__ __forceinline__ void run_flags(const uint8_t *in, uint32_t L, size_t in_stride, uint32_t x0, uint32_t &me, uint32_t &ms)
-{
-	// bytes in[x .. x+7] from a clamped address (no branch around the loads: the three words of a lane are in flight together);
-	// what lies outside [0, L) is masked out of EQ below
-	const int64_t xmax = (int64_t)in_stride - 8;
-	auto load8 = [&](int64_t x) -> uint64_t { return *reinterpret_cast<const uint64_t *>(in + min(max(x, (int64_t)0), xmax)); };
-	const uint64_t wp = load8((int64_t)x0 - 8), wc = load8((int64_t)x0), wn = load8((int64_t)x0 + 8);
-	me = 0; ms = 0;
-	if (x0 >= L) return;
-	const uint32_t w0 = (uint32_t)((wp >> 40) | (wc << 24)), s0 = (uint32_t)((wp >> 48) | (wc << 16));  // bytes x0-3.., x0-2..
-	const uint32_t w1 = (uint32_t)(wc >> 8), s1 = (uint32_t)(wc >> 16);                                  // bytes x0+1.., x0+2..
-	const uint32_t w2 = (uint32_t)((wc >> 40) | (wn << 24)), s2 = (uint32_t)((wc >> 48) | (wn << 16));  // bytes x0+5.., x0+6..
-	uint32_t EQ = eq4(w0 ^ s0) | (eq4(w1 ^ s1) << 4) | (eq4(w2 ^ s2) << 8);
-	const uint32_t lo = x0 >= 3 ? 0u : 3u - x0;              // first pair inside the input
-	const uint32_t hi = min(12u, L + 2u - x0);               // pairs i < L + 2 - x0 end inside it
-	EQ &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-	const uint32_t pv = L - x0 >= 8 ? 0xFFu : (1u << (L - x0)) - 1u;  // positions below L
-	me = EQ & (EQ >> 1) & ~(EQ >> 2) & pv;
-	ms = (EQ >> 3) & (EQ >> 4) & ~(EQ >> 2) & 0xFFu;
-}
-
-__global__ void __launch_bounds__(1024) dfl_run_count_kernel(DeflateArgs a)
-{
-	__shared__ uint32_t wsum_e[16], wsum_s[16];
+	__shared__ uint32_t wsum_e[4], wsum_s[4], base_es[2];
 	const int s = blockIdx.y;
 	const uint32_t L = a.in_sizes[s];
 	const uint32_t c = blockIdx.x;
-	if (c * RUN_CHUNK >= L) return;
+	const uint32_t c0 = c * RUNLEN_OUT;
+	if (c0 >= L) return;
 	const uint8_t *in = a.in + (size_t)s * a.in_stride;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t me, ms;
-	run_flags(in, L, a.in_stride, c * RUN_CHUNK + (uint32_t)tid * 8, me, ms);
-	const uint32_t ne = wave_sum((uint32_t)__popc(me)), ns = wave_sum((uint32_t)__popc(ms));
-	if (lane == 0) { wsum_e[wave] = ne; wsum_s[wave] = ns; }
-	__syncthreads();
-	if (tid == 0) {
-		uint32_t te = 0, ts = 0;
-		for (int w = 0; w < 16; w++) { te += wsum_e[w]; ts += wsum_s[w]; }
-		uint32_t *cnt = a.heavy_list + (size_t)s * a.in_stride;
-		cnt[2 * c] = te; cnt[2 * c + 1] = ts;
-	}
-}
-
-__global__ void __launch_bounds__(1024) dfl_run_lists_kernel(DeflateArgs a)
-{
-	__shared__ uint32_t wsum_e[16], wsum_s[16], base_es[2];
-	const int s = blockIdx.y;
-	const uint32_t L = a.in_sizes[s];
-	const uint32_t c = blockIdx.x;
-	if (c * RUN_CHUNK >= L) return;
-	const uint8_t *in = a.in + (size_t)s * a.in_stride;
+	const uint16_t *rl = a.run_len + (size_t)s * a.in_stride;
 	uint32_t *re = a.run_ends + (size_t)s * a.in_stride;
 	uint32_t *rs = re + (a.in_stride >> 2);
-	const uint32_t *cnt = a.heavy_list + (size_t)s * a.in_stride;
+	const uint32_t *cnt = a.run_counts + (size_t)s * 2 * a.run_chunks;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t x0 = c * RUN_CHUNK + (uint32_t)tid * 8;
-	// entries of the chunks before this one (wave 0 sums them while the others compute their flags)
-	if (wave == 0) {
+	const uint32_t g = c0 + (uint32_t)tid * 8;
+	// the lane's eight run-length words: one aligned 16-byte load (g is a multiple of 8; in_stride a multiple of 256)
+	uint4 wv = make_uint4(0, 0, 0, 0);
+	if (tid * 8 < RUNLEN_OUT && g < L) wv = *reinterpret_cast<const uint4 *>(rl + g);
+	const bool first_two_equal = L >= 2 && in[0] == in[1];  // the "same as before" bit of a word is only kept from position 2 on
+	if (wave == 0) {  // entries of the chunks before this one
 		uint32_t be = 0, bs = 0;
 		for (uint32_t q = lane; q < c; q += 64) { be += cnt[2 * q]; bs += cnt[2 * q + 1]; }
 		be = wave_sum(be); bs = wave_sum(bs);
 		if (lane == 0) { base_es[0] = be; base_es[1] = bs; }
 	}
-	uint32_t me, ms;
-	run_flags(in, L, a.in_stride, x0, me, ms);
+	const uint32_t w32[4] = {wv.x, wv.y, wv.z, wv.w};
+	uint32_t me = 0, ms = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const uint32_t w = (w32[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, r = w & 0x7FFFu, p = g + (uint32_t)k;
+		const bool pub = (uint32_t)tid * 8 + k < (uint32_t)RUNLEN_OUT && p < L;
+		const bool prev_eq = p >= 2 ? (w >> 15) != 0 : (p == 1 && first_two_equal);
+		me |= (uint32_t)(pub && r == 3u && p + 3 < L) << k;
+		ms |= (uint32_t)(pub && r >= 3u && !prev_eq) << k;
+	}
 	const uint32_t ne = (uint32_t)__popc(me), ns = (uint32_t)__popc(ms);
 	uint32_t inc_e = ne, inc_s = ns;
 #pragma unroll
@@ -755,17 +730,17 @@ __global__ void __launch_bounds__(1024) dfl_run_lists_kernel(DeflateArgs a)
 	if (lane == 63) { wsum_e[wave] = inc_e; wsum_s[wave] = inc_s; }
 	__syncthreads();
 	uint32_t ie = base_es[0] + inc_e - ne, is = base_es[1] + inc_s - ns, tot_e = base_es[0];
-	for (int w2 = 0; w2 < 16; w2++) {
+	for (int w2 = 0; w2 < 4; w2++) {
 		const uint32_t te = wsum_e[w2], ts = wsum_s[w2];
 		if (w2 < wave) { ie += te; is += ts; }
 		tot_e += te;
 	}
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		if ((me >> k) & 1u) re[ie++] = x0 + k;
-		if ((ms >> k) & 1u) rs[is++] = x0 + k;
+		if ((me >> k) & 1u) re[ie++] = g + k + 3;
+		if ((ms >> k) & 1u) rs[is++] = g + k;
 	}
-	if (tid == 0 && (c + 1) * RUN_CHUNK >= L) a.run_end_count[s] = tot_e;  // the slice's last chunk
+	if (tid == 0 && c0 + RUNLEN_OUT >= L) a.run_end_count[s] = tot_e;  // the slice's last chunk
 }
 
 __global__ void __launch_bounds__(256) dfl_run_info_kernel(DeflateArgs a)
@@ -1995,21 +1970,34 @@ size_t deflate_sort_temp_bytes(size_t total, int n)
 	return 0;  // the sort keeps its state in LDS (dfl_sort_pass_kernel)
 }
 
-hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st)
+// One DEFLATE pass.  `side` + `ev` (four events without timing), when given, let kernels that do not depend on each other share
+// the chip: the run lists are written while the match kernel runs (its waves fill the chip, so the side kernels mostly end
+// with it -- but they no longer come after it), and the two tail-bound matchers (long chains: a few waves walking thousands
+// of entries; runs: a binary search + scan per position) run side by side, with the Adler-32 sums behind the shorter one --
+//     main:  run lengths, sort A, sort B ─┬─ match ─────┬─ run matcher ──────────┬─ decisions, walk, symbols, trees, emit
+//     side:                               └─ run lists ─┴─ heavy matcher, Adler ─┘
+// Under stream capture this becomes the same fork / join in the graph.  Next to the SORT passes nothing may run: pass B took
+// 0.60 instead of 0.34 ms beside the run-list kernels (profiles/r03_deflate_fork.log).
+hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t sort_temp_bytes, hipStream_t st, hipStream_t side,
+                          const hipEvent_t *ev)
 {
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(a.sort_hist, 0, (size_t)n * 384 * 4, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(a.sort_hist, 0, (size_t)n * (384 + 2 * (size_t)a.run_chunks) * 4, st)) != hipSuccess) return e;  // + run_counts, right behind
 	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	(void)sort_temp; (void)sort_temp_bytes;
-	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);       // run-length words (pass A puts them into the records, the parse reads them)
+	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);       // run-length words, sort histograms, run-list counts
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<true>, dim3(n), dim3(1024), 0, st, a);   // in -> rec_in by hash & 255
 	hipLaunchKernelGGL(dfl_sort_pass_kernel<false>, dim3(n), dim3(1024), 0, st, a);  // -> rec_out by hash >> 8
-	const int nrc = (int)((a.in_stride + RUN_CHUNK - 1) / RUN_CHUNK);
-	hipLaunchKernelGGL(dfl_run_count_kernel, dim3(nrc, n), dim3(1024), 0, st, a);
-	hipLaunchKernelGGL(dfl_run_lists_kernel, dim3(nrc, n), dim3(1024), 0, st, a);   // writes over rec_in, dead after the sort
-	hipLaunchKernelGGL(dfl_run_info_kernel, dim3(8, n), dim3(256), 0, st, a);
+	const bool fork = side != nullptr && ev != nullptr;
+	hipStream_t s2 = fork ? side : st;
+	if (fork) {
+		if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(s2, ev[0], 0)) != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(dfl_run_lists_kernel, dim3(a.run_chunks, n), dim3(256), 0, s2, a);
+	hipLaunchKernelGGL(dfl_run_info_kernel, dim3(8, n), dim3(256), 0, s2, a);
 	// wide records: one 256-lane block per 256 positions (more of them in flight hide the scattered accesses better than grid-stride
 	// loops); compact records: the kernel is bound by its instructions, and 256 blocks per slice with four turns each measured best
 	// (486 us against 499 / 510 with 128 / 512, profiles/r03_match_grid.log)
@@ -2018,14 +2006,24 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	if (a.pos_mask == COMPACT_POS_MASK) hipLaunchKernelGGL(dfl_match_kernel<true>, dim3(gm, n8), dim3(256), 0, st, a, n);
 	else if (a.pos_mask == 0xFFFFFFFFu) hipLaunchKernelGGL(dfl_match_kernel<false>, dim3(gm, n8), dim3(256), 0, st, a, n);
 	else return hipErrorInvalidValue;
-	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
+	if (fork) {  // both have what the other produced: the run matcher the run lists, the heavy matcher the queue of long chains
+		if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
+		if ((e = hipEventRecord(ev[2], s2)) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(s2, ev[1], 0)) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(st, ev[2], 0)) != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(dfl_match_heavy_kernel, dim3(gx, n8), dim3(256), 0, s2, a, n);
+	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, s2, a);
 	hipLaunchKernelGGL(dfl_match_run_kernel, dim3(gx, n8), dim3(256), 0, st, a, n);
+	if (fork) {
+		if ((e = hipEventRecord(ev[3], s2)) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(st, ev[3], 0)) != hipSuccess) return e;
+	}
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_tree_kernel, dim3((a.max_blocks + TREE_BLOCKS - 1) / TREE_BLOCKS, n), dim3(64), 0, st, a);
-	hipLaunchKernelGGL(dfl_adler_kernel, dim3(n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_emit_kernel, dim3(a.max_blocks, n), dim3(256), 0, st, a);
 	return hipGetLastError();

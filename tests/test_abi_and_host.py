@@ -105,7 +105,8 @@ def test_options_round_trip_without_a_device():
                              (b"decode_slots", 5, 2), (b"tile_path", 3, 3), (b"tile_path", 4, 4),
                              (b"tile_path", 9, 1), (b"device_inflate", 5, 1), (b"deflate_graph", 0, 0), (b"deflate_graph", 1, 1),
                              (b"deflate_compact_records", 0, 0), (b"deflate_compact_records", 3, 1),
-                             (b"decode_yields", 0, 0), (b"decode_yields", 2, 1)):
+                             (b"decode_yields", 0, 0), (b"decode_yields", 2, 1), (b"queue_ahead", 0, 0), (b"queue_ahead", 1, 1),
+                             (b"deflate_fork", 0, 0), (b"deflate_fork", 1, 1)):
         assert L.cct_set_option(key, given) == 0
         assert L.cct_get_option(key, C.byref(v)) == 0 and v.value == want, (key, given, v.value)
     assert L.cct_set_option(b"encode_slots", 1) == 0 and L.cct_set_option(b"tile_path", 1) == 0

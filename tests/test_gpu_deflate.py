@@ -74,6 +74,11 @@ def test_both_sort_record_layouts(hip):
     finally:
         _ffi.check(L.cct_set_option(b"deflate_compact_records", 1))
     _check(hip, blobs)
+    try:  # the pass in one stream (no side branch)
+        _ffi.check(L.cct_set_option(b"deflate_fork", 0))
+        _check(hip, blobs)
+    finally:
+        _ffi.check(L.cct_set_option(b"deflate_fork", 1))
     big = np.tile(np.frombuffer(oracle.encode(gi.ct_phantom(1), deflate=False)[13:], dtype=np.uint8), 18)[: (1 << 22) + 70001]
     big = big.copy()
     big[::4099] ^= 0x55  # not one period repeated
