@@ -256,6 +256,13 @@ int ensure_ctx(int device)
 		HIP_TRY(hipSetDevice(g_ctx.device));
 		return CCT_OK;
 	}
+	// The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  The library keeps up to eight
+	// streams busy (two encode slots with copy and side streams, two decode slots, the size gather), and two streams on one queue
+	// run one after the other: with a stream more than before, the packed-archive copy and the next DEFLATE pass shared a queue
+	// and a 1024^2 pass started 3 ms late (BASELINE configs[3]: 14.9 K instead of 17 K MPixels/s); with another assignment the
+	// side branch of a pass shared one with the decode (configs[1]: DEFLATE 4.1 instead of 3.6 ms).  Eight queues, unless the
+	// user has set the variable; it is read when the runtime initialises, i.e. by the first HIP call of the process below.
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int count = 0;
 	hipError_t e = hipGetDeviceCount(&count);
 	if (e != hipSuccess || count <= 0)
@@ -282,7 +289,6 @@ int ensure_ctx(int device)
 			HIP_TRY(hipEventCreate(&E.ev_z1s[q]));
 			HIP_TRY(hipEventCreateWithFlags(&E.ev_small[q], hipEventDisableTiming));
 		}
-		HIP_TRY(hipStreamCreateWithFlags(&E.stream_side, hipStreamNonBlocking));
 		for (int q = 0; q < 4; q++) HIP_TRY(hipEventCreateWithFlags(&E.ev_fork[q], hipEventDisableTiming));
 	}
 	for (int k = 0; k < N_DEC_SLOTS; k++) {
@@ -840,6 +846,12 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 	// cross-stream dependencies cost more than the overlap returned, here as in the transform+pack stage)
 	const size_t tmp = (deflate_sort_temp_bytes((size_t)n * in_stride, n) + 511) & ~(size_t)255;
 	if ((rc = E.z_sorttmp.ensure(tmp + 256))) return rc;
+	const bool use_fork = g_ctx.deflate_fork != 0;
+	if (use_fork && !E.stream_side) {
+		// created on first use (see GPU_MAX_HW_QUEUES in ensure_ctx: streams are not free)
+		const int crc = exclusive_section([&]() -> int { HIP_TRY(hipStreamCreateWithFlags(&E.stream_side, hipStreamNonBlocking)); return CCT_OK; });
+		if (crc) return crc;
+	}
 	DeflateArgs a{};
 	a.in = d_in; a.in_stride = in_stride; a.in_sizes = d_in_sizes;
 	a.rec_in = (uint64_t *)E.z_vals_in.p; a.rec_out = (uint64_t *)E.z_vals_out.p;
@@ -873,7 +885,8 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 		std::vector<uint8_t> key(sizeof(DeflateArgs) + 2 * sizeof(int));
 		memcpy(key.data(), &a, sizeof(DeflateArgs));
 		memcpy(key.data() + sizeof(DeflateArgs), &n, sizeof(int));
-		memcpy(key.data() + sizeof(DeflateArgs) + sizeof(int), &g_ctx.deflate_fork, sizeof(int));
+		const int fork_key = use_fork ? 1 : 0;
+		memcpy(key.data() + sizeof(DeflateArgs) + sizeof(int), &fork_key, sizeof(int));
 		EncSlot::ZGraph *zg = nullptr;
 		for (auto &g : E.z_graphs) if (g.key == key) zg = &g;
 		if (!zg) {
@@ -887,7 +900,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 				}
 				EncSlot::ZGraph g;
 				HIP_TRY(hipStreamBeginCapture(E.stream, hipStreamCaptureModeThreadLocal));
-				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, g_ctx.deflate_fork ? E.stream_side : nullptr, E.ev_fork);
+				hipError_t le = launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, use_fork ? E.stream_side : nullptr, E.ev_fork);
 				hipError_t ce = hipStreamEndCapture(E.stream, &g.graph);
 				if (le != hipSuccess) { if (g.graph) (void)hipGraphDestroy(g.graph); return fail(CCT_E_DEVICE, "DEFLATE capture: %s", hipGetErrorString(le)); }
 				HIP_TRY(ce);
@@ -904,7 +917,7 @@ int deflate_locked(EncSlot &E, const uint8_t *d_in, size_t in_stride, const uint
 		HIP_TRY(hipGraphLaunch(zg->exec, E.stream));
 		return CCT_OK;
 	}
-	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, g_ctx.deflate_fork ? E.stream_side : nullptr, E.ev_fork));
+	HIP_TRY(launch_deflate(a, n, E.z_sorttmp.p, tmp, E.stream, use_fork ? E.stream_side : nullptr, E.ev_fork));
 	return CCT_OK;
 }
 

@@ -397,14 +397,16 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 		// >= 3 three bytes on (exactly three equal bytes from p, the fourth inside the input) and starts one when >= 3 equal bytes
 		// follow and the byte before differs
 		{
-			uint32_t ce = 0, cs = 0;  // wave totals (ballots: scalar popcounts instead of a shuffle reduction)
+			uint32_t me = 0, ms = 0;
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
 				const bool pub = threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT && g + k < L;
 				const uint32_t r = out[k] & 0x7FFFu;
-				ce += (uint32_t)__popcll(__ballot(pub && r == 3u && g + k + 3 < L));
-				cs += (uint32_t)__popcll(__ballot(pub && r >= 3u && !(g + k >= 1 && b[k] == b[k + 1])));
+				me |= (uint32_t)(pub && r == 3u && g + k + 3 < L) << k;
+				ms |= (uint32_t)(pub && r >= 3u && !(g + k >= 1 && b[k] == b[k + 1])) << k;
 			}
+			uint32_t ce = 0, cs = 0;  // wave totals; run boundaries are rare (inside a long run there is none): most waves skip this
+			if (__any((me | ms) != 0)) { ce = wave_sum((uint32_t)__popc(me)); cs = wave_sum((uint32_t)__popc(ms)); }
 			if (lane == 0 && (ce | cs)) {  // (counters zeroed with the sort histograms: no barrier, no store where there is no run)
 				uint32_t *cnt = a.run_counts + (size_t)s * 2 * a.run_chunks;
 				if (ce) atomicAdd(&cnt[2 * c], ce);
@@ -1915,6 +1917,10 @@ __global__ void dfl_offsets_kernel(DeflateArgs a, int n)
 		for (int s = threadIdx.x; s < n; s += blockDim.x) { a.postloop_lit[s] = 0; a.heavy_count[s] = 0; a.deep_count[s] = 0; a.run_end_count[s] = 0; }  // (run_end_count: an empty slice has no chunk that would write it)
 		if (threadIdx.x == 0) *a.gen = *a.gen % GEN_MAX + 1u;  // tag of this pass's match records (see MatchRec)
 	}
+	// run-list counters of dfl_run_len_kernel (a memset node of a few megabytes at the head of the graph waited for the copy
+	// engine: with the files of the pass before still on the wire a pass of 1024^2 slices started 3 ms late)
+	const size_t nrc = (size_t)n * 2 * (size_t)a.run_chunks;
+	for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nrc; t += (size_t)gridDim.x * blockDim.x) a.run_counts[t] = 0;
 }
 
 }  // namespace
@@ -1983,8 +1989,8 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 {
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.out, 0, (size_t)n * a.out_stride, st)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(a.sort_hist, 0, (size_t)n * (384 + 2 * (size_t)a.run_chunks) * 4, st)) != hipSuccess) return e;  // + run_counts, right behind
-	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(1), dim3(256), 0, st, a, n);
+	if ((e = hipMemsetAsync(a.sort_hist, 0, (size_t)n * 384 * 4, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(dfl_offsets_kernel, dim3(64), dim3(256), 0, st, a, n);  // (also zeroes run_counts)
 	const int gx = (int)std::min<size_t>(64, (a.in_stride + 255) / 256);
 	(void)sort_temp; (void)sort_temp_bytes;
 	hipLaunchKernelGGL(dfl_run_len_kernel, dim3(gx, n), dim3(256), 0, st, a);       // run-length words, sort histograms, run-list counts

@@ -243,7 +243,8 @@ def main():
         _ffi.check(L.cct_set_option(b"queue_ahead", 0))
     for env, key in (("CCT_WG_THREADS", b"wg_threads"), ("CCT_DEFLATE_GRAPH", b"deflate_graph"),
                      ("CCT_DEVICE_INFLATE", b"device_inflate"), ("CCT_TILE_PATH", b"tile_path"),
-                     ("CCT_ENCODE_SLOTS", b"encode_slots")):
+                     ("CCT_ENCODE_SLOTS", b"encode_slots"), ("CCT_INFLATE_LANES", b"inflate_lanes"),
+                     ("CCT_DEFLATE_FORK", b"deflate_fork")):
         if os.environ.get(env):
             _ffi.check(L.cct_set_option(key, int(os.environ[env])))
     dev_deflate, dev_inflate = C.c_int(0), C.c_int(0)
