@@ -452,16 +452,20 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 				// A lane's <= 16 pixels fall into at most two stream slots: both slots' entry, partner and tile data are fetched
 				// before the loop.  The loop itself runs over the 16 byte positions with a compile-time index (a byte is a bit-field
 				// extract, not a select chain) and skips the positions that open no pixel token.
-				struct SlotInfo { uint32_t kind, blk0, blk1, org0, org1, pat0, pat1; };
+				// per slot and parity (leader / partner of a meshed pair): first traversal position of the block, the tile's raster
+				// origin and the index of the block's first pattern entry (the table is padded by one entry per 16 positions) -- a
+				// pixel then costs one select of each instead of rebuilding them from block numbers
+				struct SlotInfo { uint32_t kind, pos0, pos1, org0, org1, idx0, idx1; };
 				auto slot_info = [&](uint32_t sl) {
 					SlotInfo si{0, 0, 0, 0, 0, 0, 0};
 					const uint32_t ent = slot_rd(min(sl, (uint32_t)NB - 1u));
-					si.blk0 = ent & 0x3FFFFFFFu; si.kind = ent >> 30;
-					si.blk1 = si.kind ? si.blk0 + role_rd(si.blk0) : si.blk0;
+					const uint32_t blk0 = ent & 0x3FFFFFFFu; si.kind = ent >> 30;
+					const uint32_t blk1 = si.kind ? blk0 + role_rd(blk0) : blk0;
+					si.pos0 = blk0 * BS; si.pos1 = blk1 * BS;
 					if (TILED) {
-						const uint32_t t0 = (si.blk0 * BS) >> 12, t1 = (si.blk1 * BS) >> 12;
-						si.org0 = l_torg[t0]; si.pat0 = (uint32_t)l_tori[t0] * PAT_STRIDE;
-						si.org1 = l_torg[t1]; si.pat1 = (uint32_t)l_tori[t1] * PAT_STRIDE;
+						const uint32_t t0 = si.pos0 >> 12, t1 = si.pos1 >> 12, b0 = si.pos0 & 4095u, b1 = si.pos1 & 4095u;
+						si.org0 = l_torg[t0]; si.idx0 = (uint32_t)l_tori[t0] * PAT_STRIDE + b0 + (b0 >> 4);
+						si.org1 = l_torg[t1]; si.idx1 = (uint32_t)l_tori[t1] * PAT_STRIDE + b1 + (b1 >> 4);
 					}
 					return si;
 				};
@@ -476,21 +480,18 @@ __global__ void __launch_bounds__(1024) decode_kernel(DecArgs a)
 					const uint32_t c1 = (ws[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu;
 					// (reserved tags 110xxxxx / 1111xxxx: no branch of core.py:500-516 is taken, the previous pixel repeats)
 					val += ((sm.S >> i) & 1u) ? tok_delta_short(c) : ((fulls >> i) & 1u) ? tok_delta_full(c, c1) : 0;
-					if (val < 0 || val > 65535) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506
+					if ((uint32_t)val > 65535u) flags |= CCT_ST_OVERFLOW;  // to_bytes(2), core.py:506 (negative or too large)
 					const uint32_t sl = ord / BS, t = ord % BS;
 					const bool inA = sl == slA;
 					const uint32_t kind = inA ? A.kind : B.kind;
 					uint32_t odd = 0, off = t;
 					if (kind) { const uint32_t mm = (kind - 1u) * BS + t; odd = mm & 1u; off = mm >> 1; }  // index inside the 2*bs interleave
-					const uint32_t blk = inA ? (odd ? A.blk1 : A.blk0) : (odd ? B.blk1 : B.blk0);
-					const uint32_t pos = blk * BS + off;
 					uint32_t ras;
 					if (TILED) {
 						const uint32_t org = inA ? (odd ? A.org1 : A.org0) : (odd ? B.org1 : B.org0);
-						const uint32_t pat = inA ? (odd ? A.pat1 : A.pat0) : (odd ? B.pat1 : B.pat0);
-						const uint32_t p = pos & 4095u;
-						ras = org + l_pat[pat + p + (p >> 4)];
-					} else ras = raster_of(pos);
+						const uint32_t idx = inA ? (odd ? A.idx1 : A.idx0) : (odd ? B.idx1 : B.idx0);
+						ras = org + l_pat[idx + off + (BS > 16 ? off >> 4 : 0u)];  // (off < BS: inside the block)
+					} else ras = raster_of((inA ? (odd ? A.pos1 : A.pos0) : (odd ? B.pos1 : B.pos0)) + off);
 					out[ras] = (uint16_t)val;
 					ord++;
 				}

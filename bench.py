@@ -456,6 +456,20 @@ def main():
             "inflate": roof("inflate_kernel (device INFLATE)", file_per_launch + payload_per_launch, inflate_ms),
             "decode": roof("decode_kernel (tokens -> raster)", payload_per_launch + 2.0 * npx, dec_ms),
         }
+        # per-kernel HBM bytes of these stages from the committed PMC passes (serial calls on this workload, profiles/): a record,
+        # not a live measurement -- FETCH_SIZE / WRITE_SIZE in KB as counted, per dispatch
+        if args.config == 2 and n == 256:
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03_pmc_codec.json")) as f:
+                    pk = json.load(f)["kernels"]
+                def kb(names):
+                    return {k: {"FETCH_SIZE_KB": v.get("FETCH_SIZE_KB"), "WRITE_SIZE_KB": v.get("WRITE_SIZE_KB")}
+                            for k, v in pk.items() if k.startswith(names)}
+                others["deflate"]["pmc_per_kernel"] = dict(kb(("dfl_",)), source="profiles/r03_pmc_codec.json")
+                others["inflate"]["pmc_per_kernel"] = dict(kb(("inflate_",)), source="profiles/r03_pmc_codec.json")
+                others["decode"]["pmc_per_kernel"] = dict(kb(("decode_",)), source="profiles/r03_pmc_codec.json")
+            except (OSError, KeyError, ValueError):
+                pass
         if decode_only:
             main_roof = roof("decode stages: inflate_kernel + decode_kernel (archive -> rasters)", file_per_launch + 2.0 * npx,
                              inflate_ms + dec_ms, {"traffic": None, "traffic_source": None})
