@@ -26,6 +26,9 @@
  * overwrites their buffers.  Rare runtime work -- capturing and instantiating a slot's graphs, growing a workspace,
  * creating a stream -- is done with no other call of the library in flight (the other calls finish first; a
  * call that arrives meanwhile waits a few milliseconds): this happens on the first batches of a shape only.
+ * The library keeps up to eight HIP streams busy; the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware
+ * queues (default 4) and two streams on one queue run one after the other, so the first device call sets that variable to 8
+ * unless the caller has set it (it is read when the HIP runtime initialises: set it yourself if HIP is up before this library).
  * The library initialises HIP lazily on the first device call.  Processes that fork
  * workers (scripts/evaluate.py:107) must fork BEFORE that call: each child then binds the
  * GPU itself.  A child forked after its parent initialised the GPU gets CCT_E_DEVICE from
