@@ -319,18 +319,18 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
 		const uint32_t c0 = c * RUNLEN_OUT;
 		const uint32_t g = c0 + threadIdx.x * 8;  // first of this lane's 8 positions
-		uint8_t b[11];                            // in[g-1 .. g+9]
-		if (g + 10 <= L && g >= 1) {
+		uint8_t b[12];                            // in[g-1 .. g+10]
+		if (g + 12 <= L && g >= 1) {
 			uint64_t w;
 			__builtin_memcpy(&w, in + g, 8);
 #pragma unroll
 			for (int k = 0; k < 8; k++) b[k + 1] = (uint8_t)(w >> (8 * k));
 			b[0] = in[g - 1];
-			uint16_t w2; __builtin_memcpy(&w2, in + g + 8, 2);
-			b[9] = (uint8_t)w2; b[10] = (uint8_t)(w2 >> 8);
+			uint32_t w2; __builtin_memcpy(&w2, in + g + 8, 4);
+			b[9] = (uint8_t)w2; b[10] = (uint8_t)(w2 >> 8); b[11] = (uint8_t)(w2 >> 16);
 		} else {
 #pragma unroll
-			for (int k = 0; k < 11; k++) { const int64_t y = (int64_t)g - 1 + k; b[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
+			for (int k = 0; k < 12; k++) { const int64_t y = (int64_t)g - 1 + k; b[k] = (y >= 0 && y < (int64_t)L) ? in[y] : 0; }
 		}
 		// the sort's digit histograms (UPDATE_HASH of the three bytes from every published position that starts a string).
 		// A quarter of a CT payload is runs of one byte: a lane whose strings all hash alike adds them in one go, and so does
@@ -397,14 +397,18 @@ __global__ void __launch_bounds__(256) dfl_run_len_kernel(DeflateArgs a)
 		// >= 3 three bytes on (exactly three equal bytes from p, the fourth inside the input) and starts one when >= 3 equal bytes
 		// follow and the byte before differs
 		{
-			uint32_t me = 0, ms = 0;
+			// from the "changes after this byte" bits of in[g-1 .. g+9] (bit i: in[g-1+i] != in[g+i], or the right byte is past the
+			// end, or -- bit 0 -- there is no byte before position 0): position p = g+k, pair p <-> bit k+1
+			uint32_t cx = g == 0 ? 1u : 0u;
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				const bool pub = threadIdx.x * 8 + k < (uint32_t)RUNLEN_OUT && g + k < L;
-				const uint32_t r = out[k] & 0x7FFFu;
-				me |= (uint32_t)(pub && r == 3u && g + k + 3 < L) << k;
-				ms |= (uint32_t)(pub && r >= 3u && !(g + k >= 1 && b[k] == b[k + 1])) << k;
-			}
+			for (int i = 0; i < 11; i++) cx |= (uint32_t)(b[i] != b[i + 1] || g + (uint32_t)i >= L) << i;
+			const uint32_t t8 = threadIdx.x * 8;
+			const uint32_t npub = t8 < (uint32_t)RUNLEN_OUT ? min(min(8u, (uint32_t)RUNLEN_OUT - t8), g < L ? L - g : 0u) : 0u;  // published positions of the lane
+			const uint32_t pubm = (1u << npub) - 1u;
+			const uint32_t ne3 = g + 3 < L ? min(8u, L - 3u - g) : 0u;                 // positions with p + 3 < L
+			const uint32_t run3 = ~(cx >> 1) & ~(cx >> 2);                             // three equal bytes from p
+			const uint32_t me = run3 & (cx >> 3) & pubm & ((1u << ne3) - 1u);          // ... and the fourth differs, inside the input
+			const uint32_t ms = run3 & cx & pubm;                                      // ... and the byte before differs
 			uint32_t ce = 0, cs = 0;  // wave totals; run boundaries are rare (inside a long run there is none): most waves skip this
 			if (__any((me | ms) != 0)) { ce = wave_sum((uint32_t)__popc(me)); cs = wave_sum((uint32_t)__popc(ms)); }
 			if (lane == 0 && (ce | cs)) {  // (counters zeroed with the sort histograms: no barrier, no store where there is no run)
@@ -876,17 +880,25 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 	const uint32_t nblk64 = (L + 63) / 64;
 	const int lane = threadIdx.x & 63;
 	const uint32_t gen = *a.gen;
-	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
+	// the lane's own record and its right neighbour's (what the first deferral test reads) are requested together and without a
+	// branch (a load inside a conditional is waited for on the spot, which made them two round trips in a row), one turn ahead
+	const uint32_t lastp = npos ? npos - 1 : 0;
+	const uint32_t wb_step = gridDim.x * (blockDim.x >> 6);
+	struct Req { MatchRec m0, m1; uint32_t w0, w1; };
+	auto request = [&](uint32_t wb) {
+		const uint32_t p = wb * 64 + lane, pa = min(p, lastp), pb = min(p + 1, lastp);
+		return Req{mr[pa], mr[pb], rl[pa], rl[pb]};
+	};
+	const uint32_t wb0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	Req nx = request(wb0);
+	for (uint32_t wb = wb0; wb < nblk64; wb += wb_step) {
 		const uint32_t p = wb * 64 + lane;
 		const uint32_t blk_end = wb * 64 + 64;
 		uint32_t rec = 0, nxt = blk_end, cnt = 0;
-		// the lane's own record and its right neighbour's (what the first deferral test reads) are requested together and
-		// without a branch: a load inside a conditional is waited for on the spot, which made them two round trips in a row
-		const uint32_t lastp = npos ? npos - 1 : 0;
 		const uint32_t pa = min(p, lastp), pb = min(p + 1, lastp);
-		const MatchRec m0 = mr[pa], m1 = mr[pb];
-		const uint32_t w0 = rl[pa], w1 = rl[pb];
-		const MatchRec r0 = checked_match(m0, gen, w0, pa, L), r1 = checked_match(m1, gen, w1, pb, L);
+		const Req cq = nx;
+		nx = request(wb + wb_step);
+		const MatchRec r0 = checked_match(cq.m0, gen, cq.w0, pa, L), r1 = checked_match(cq.m1, gen, cq.w1, pb, L);
 		if (p < L) {
 			int len, dist;
 			match_of(r0, p, npos, 2, len, dist);
@@ -986,15 +998,23 @@ __global__ void __launch_bounds__(256) dfl_symbols_kernel(DeflateArgs a)
 	const int lane = threadIdx.x & 63;
 	uint32_t *sym = a.sym + base;
 	uint32_t *bend = a.blk_end + (size_t)s * a.max_blocks;
-	for (uint32_t wb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wb < nblk64; wb += gridDim.x * (blockDim.x >> 6)) {
-		// everything the block needs is requested up front and without a branch (a load inside a conditional is waited for on the
-		// spot: entry, record, symbol base and the literal byte used to be four round trips in a row)
+	// everything a block needs is requested without a branch (a load inside a conditional is waited for on the spot: entry,
+	// record, symbol base and the literal byte used to be four round trips in a row) -- and one turn ahead
+	const uint32_t wb_step = gridDim.x * (blockDim.x >> 6), wb_last = nblk64 ? nblk64 - 1 : 0;
+	struct Req { uint32_t entry, symbase, rec; uint8_t lit0; };
+	auto request = [&](uint32_t wb) {
+		const uint32_t wbc = min(wb, wb_last), pc = min(wbc * 64 + lane, L - 1);  // L > 0 where the loop runs
+		return Req{a.blk_entry[bbase + wbc], a.blk_symbase[bbase + wbc], a.rec32[base + pc], in[pc]};
+	};
+	const uint32_t wb0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	Req nx = nblk64 ? request(wb0) : Req{0xFFFFFFFFu, 0, 0, 0};
+	for (uint32_t wb = wb0; wb < nblk64; wb += wb_step) {
 		const uint32_t p = wb * 64 + lane;
-		const uint32_t pc = min(p, L - 1);  // L > 0: nblk64 > 0
-		const uint32_t entry = a.blk_entry[bbase + wb];
-		const uint32_t symbase = a.blk_symbase[bbase + wb];
-		uint32_t rec = a.rec32[base + pc];
-		const uint8_t lit0 = in[pc];
+		const Req cur_req = nx;
+		nx = request(wb + wb_step);
+		const uint32_t entry = cur_req.entry, symbase = cur_req.symbase;
+		uint32_t rec = cur_req.rec;
+		const uint8_t lit0 = cur_req.lit0;
 		if (entry == 0xFFFFFFFFu) continue;  // block jumped over by a match
 		if (p >= L) rec = 0;
 		const uint32_t k = rec & 0xFFu, len = (rec >> 8) & 0x1FFu, dist = rec >> 17;
