@@ -690,7 +690,8 @@ __global__ void __launch_bounds__(256) dfl_match_heavy_kernel(DeflateArgs a, int
 // offset (a workgroup prefix sum places them, so both lists come out in position order); dfl_run_info_kernel pairs the k-th
 // start with the k-th end (run length without scanning).  Until round 3 one workgroup per slice walked its 8192-byte
 // chunks in a row, computing the flags byte by byte (0.18 ms per batch).
-// Buffer (in_stride words of its own, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4).
+// Buffer (in_stride words of its own, at most L/4 runs): ends at [0, 1/4), starts at [1/4, 1/2), length|byte<<16 at [1/2, 3/4),
+// rank of every eighth position among the ends at [3/4, 1) (in_stride / 8 words).
 __global__ void __launch_bounds__(256) dfl_run_lists_kernel(DeflateArgs a)
 {
 	__shared__ uint32_t wsum_e[4], wsum_s[4], base_es[2];
@@ -741,6 +742,9 @@ __global__ void __launch_bounds__(256) dfl_run_lists_kernel(DeflateArgs a)
 		if (w2 < wave) { ie += te; is += ts; }
 		tot_e += te;
 	}
+	// rank table for the run matcher: ends put on the list by the positions before g (last quarter of the slice's buffer): the
+	// "last run end <= p" of a position is then one lookup and a step or two instead of a binary search of twelve dependent loads
+	if ((uint32_t)tid * 8 < (uint32_t)RUNLEN_OUT && g < L) re[3 * (a.in_stride >> 2) + (g >> 3)] = ie;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
 		if ((me >> k) & 1u) re[ie++] = g + k + 3;
@@ -820,8 +824,13 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 			uint32_t qmin4 = qw, qmin1 = qw;
 			if (i >= 4096 && rec_hash(r_4096) == h) qmin4 = max(qmin4, rec_pos(r_4096, a.pos_mask));
 			if (i >= 1024 && rec_hash(r_1024) == h) qmin1 = max(qmin1, rec_pos(r_1024, a.pos_mask));
-			uint32_t lo = 0, hi = nre;  // last run end <= p (none lies strictly inside p's own run)
-			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (re[mid] <= p) lo = mid + 1; else hi = mid; }
+			// number of run ends <= p (none lies strictly inside p's own run): an end x comes from position x - 3, so these are the
+			// entries of the positions below p - 2 -- the rank table gives those below the 8-aligned part, the rest is a step or two
+			uint32_t lo = 0;
+			if (p >= 3) {
+				lo = re[3 * (a.in_stride >> 2) + ((p - 2) >> 3)];
+				while (lo < nre && re[lo] <= p) lo++;
+			}
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
 				const uint32_t x = re[t];
 				if (x < qmin4 + 3) break;          // even q = x-3 is outside the first 4096 entries / the window
