@@ -831,10 +831,13 @@ __global__ void __launch_bounds__(256) dfl_match_run_kernel(DeflateArgs a, int n
 				lo = re[3 * (a.in_stride >> 2) + ((p - 2) >> 3)];
 				while (lo < nre && re[lo] <= p) lo++;
 			}
+			// (the entry of the next step is requested before this one is evaluated: the loop is a chain of dependent lookups otherwise)
+			uint32_t x_n = lo ? re[lo - 1] : 0u, lw_n = lo ? rl[lo - 1] : 0u;
 			for (int64_t t = (int64_t)lo - 1; t >= 0; t--) {
-				const uint32_t x = re[t];
+				const uint32_t x = x_n;
+				const uint32_t lw = lw_n;          // min(run length, 511) | run byte << 16
+				{ const int64_t tn = t > 0 ? t - 1 : 0; x_n = re[tn]; lw_n = rl[tn]; }
 				if (x < qmin4 + 3) break;          // even q = x-3 is outside the first 4096 entries / the window
-				const uint32_t lw = rl[t];         // min(run length, 511) | run byte << 16
 				if ((lw >> 16) != b) continue;     // a run of another byte
 				const uint32_t m = min(min(lw & 0xFFFFu, r), x - qmin4);  // run length counted down to qmin4, capped at r
 				if (m >= 3) {
