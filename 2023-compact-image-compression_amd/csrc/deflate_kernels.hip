@@ -621,9 +621,12 @@ __device__ __forceinline__ void coop_longest_match(const uint8_t *in, const uint
 	uint32_t best_q = 0;
 	int len1024 = -1;
 	uint32_t q1024 = 0;
+	auto rec_of_round = [&](int r) { const int64_t j = (int64_t)i - 1 - (int64_t)(r * 64 + lane); return recs[j >= 0 ? j : 0]; };
+	uint64_t rj_next = rec_of_round(0);
 	for (int r = 0; r < 64; r++) {  // 64 x 64 = max_chain_length 4096 candidates
 		const int64_t j = (int64_t)i - 1 - (int64_t)(r * 64 + lane);
-		const uint64_t rj = j >= 0 ? recs[j] : ~0ull;
+		const uint64_t rj = j >= 0 ? rj_next : ~0ull;
+		rj_next = rec_of_round(r + 1);  // (requested before this round's strings are compared)
 		const bool in_chain = j >= 0 && rec_hash(rj) == h;
 		const uint32_t q = in_chain ? rec_pos(rj, pos_mask) : 0u;
 		const uint32_t dist = p - q;
