@@ -947,15 +947,19 @@ __global__ void __launch_bounds__(256) dfl_rec_kernel(DeflateArgs a)
 // ------------------------------------------------------------------ 3b. block-to-block walk (one workgroup per slice)
 // The parse enters 64-position block b at exit_pos[previous entry]; that hop chain is serial (~4500 hops per
 // slice), but its only state is the position, and chains that start at different positions merge as soon as
-// they share one decision position.  So the slice is cut into 256 segments: every lane hops through its own
+// they share one decision position.  So the slice is cut into WALK_T segments: every lane hops through its own
 // segment from a speculative start (the segment boundary), then restarts from where its predecessor really
 // landed until no start moves any more (lane k is final after k passes at the latest; typically 2-3 passes
 // of ~18 hops).  A prefix sum over the symbol counts gives every lane its symbol base, and a last pass
 // publishes entry position and symbol base of every block the parse really enters.
-__global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
+#ifndef CCT_WALK_T
+#define CCT_WALK_T 256
+#endif
+constexpr int WALK_T = CCT_WALK_T;  // lanes (= segments) per slice; measured per batch: 128: 85, 256: 77, 512: 89, 1024: 163 us (more segments, more restart passes)
+__global__ void __launch_bounds__(WALK_T) dfl_walk_kernel(DeflateArgs a, int n)
 {
-	__shared__ uint32_t s_land[256];
-	__shared__ uint32_t s_wsum[4];
+	__shared__ uint32_t s_land[WALK_T];
+	__shared__ uint32_t s_wsum[WALK_T / 64];
 	const int s = blockIdx.x;
 	(void)n;
 	const uint32_t L = a.in_sizes[s];
@@ -963,7 +967,7 @@ __global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 	const size_t bbase = (size_t)s * (a.in_stride / 64);
 	const uint32_t *exit_rec = a.exit_pos + base;  // (offset of the exit past the entry's block) | symbols << 16
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t seg = (((L + 255) / 256) + 63) & ~63u;
+	const uint32_t seg = (((L + WALK_T - 1) / WALK_T) + 63) & ~63u;
 	const uint32_t seg_end = min(L, (uint32_t)(tid + 1) * seg);
 	uint32_t start = min(L, (uint32_t)tid * seg), land = start, cnt = 0;
 	auto hop_through = [&]() {
@@ -989,7 +993,7 @@ __global__ void __launch_bounds__(256) dfl_walk_kernel(DeflateArgs a, int n)
 	__syncthreads();
 	uint32_t syms = inc - cnt;
 	for (int w = 0; w < wave; w++) syms += s_wsum[w];
-	if (tid == 255) a.total_syms[s] = syms + cnt;
+	if (tid == WALK_T - 1) a.total_syms[s] = syms + cnt;
 	for (uint32_t cur = start; cur < seg_end;) {
 		const uint32_t b = cur >> 6;
 		a.blk_entry[bbase + b] = cur;
@@ -2062,7 +2066,7 @@ hipError_t launch_deflate(const DeflateArgs &a, int n, void *sort_temp, size_t s
 	}
 	hipLaunchKernelGGL(dfl_rec_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_offsets2_kernel, dim3(256), dim3(256), 0, st, a, n);
-	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(256), 0, st, a, n);
+	hipLaunchKernelGGL(dfl_walk_kernel, dim3(n), dim3(WALK_T), 0, st, a, n);
 	hipLaunchKernelGGL(dfl_symbols_kernel, dim3(gx, n), dim3(256), 0, st, a);
 	hipLaunchKernelGGL(dfl_tree_kernel, dim3((a.max_blocks + TREE_BLOCKS - 1) / TREE_BLOCKS, n), dim3(64), 0, st, a);
 	hipLaunchKernelGGL(dfl_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, n);
