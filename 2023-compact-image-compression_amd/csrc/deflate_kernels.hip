@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// 64 (running per-digit counts in its own LDS row), so the cross-wave prefix and its two barriers are paid
 	// once per 4096 elements.  Loads of the next tile are issued before the current one is ranked.
 #ifndef CCT_SORT_E
-#define CCT_SORT_E 4
+#define CCT_SORT_E 8  // pass B per batch: 2: 366, 4: 359, 8: 330-343 us; 12 spills (1318 us)
 #endif
-	constexpr int E = CCT_SORT_E;
+	constexpr int E = FIRST ? 4 : CCT_SORT_E;  // (pass A: one input dword per lane covers its 256 positions)
 	// Loads of the next tile are issued before the current one is ranked and taken after it.  Two things the compiler did with
 	// the obvious code: inside a conditional it waits for every load right where it is issued (s_waitcnt vmcnt(0) before the
 	// join), which made the "prefetch" four full memory round trips in a row per tile; and it moved the first use of the
