@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 #ifndef CCT_SORT_E
 #define CCT_SORT_E 8  // pass B per batch: 2: 366, 4: 359, 8: 330-343 us; 12 spills (1318 us)
 #endif
-	constexpr int E = FIRST ? 4 : CCT_SORT_E;  // (pass A: one input dword per lane covers its 256 positions)
+	constexpr int E = CCT_SORT_E;
+	constexpr int ND = E / 4;  // pass A: input dwords per lane (a wave's tile = 64 E positions = 16 E dwords)
 	// Loads of the next tile are issued before the current one is ranked and taken after it.  Two things the compiler did with
 	// the obvious code: inside a conditional it waits for every load right where it is issued (s_waitcnt vmcnt(0) before the
 	// join), which made the "prefetch" four full memory round trips in a row per tile; and it moved the first use of the
@@ -158,12 +159,12 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// in-order counter).  So: the index is clamped instead of tested, the raw values pass through an empty asm right before
 	// the stores (that is where the wait lands), and hash / position are derived after it.
 	const uint32_t last = npos ? npos - 1 : 0;
-	// Pass A reads the input as aligned dwords: the 256 positions of a wave's tile need bytes [B, B + 260), lane l loads the dword
-	// at B + 4 l and everybody the one at B + 256; a position takes its two dwords from the lanes that hold them (ds_bpermute) and
+	// Pass A reads the input as aligned dwords: the 64 E positions of a wave's tile need bytes [B, B + 64 E + 4), lane l loads the dwords
+	// at B + 256 d + 4 l and everybody the one after the tile; a position takes its two dwords from the lanes that hold them (ds_bpermute) and
 	// shifts its five bytes out.  (One byte-granular load per position and field was tried first: the pass went 0.44 -> 0.59 ms,
 	// the address unit handles such loads lane by lane.)  Bytes past the end of the slice are whatever the buffer holds: the hash
 	// of a valid position (p < L - 2) never sees them, and the match kernel does not use the compact fields of the last positions.
-	static_assert(!FIRST || E == 4, "pass A: one dword per lane covers the 256 positions of a wave's tile");
+	static_assert(E % 4 == 0 && ND + 1 <= E, "pass A: whole dwords per lane, kept in ra[0 .. ND]");
 #ifdef CCT_SORT_PROBE  // tuning builds only (results invalid)
 	const bool compact = false;
 #else
@@ -173,8 +174,9 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// tile_base = first element of this wave's 256; ra/rb = the values as loaded: anything computed here is computed (and waited for) early
 	auto fetch = [&](uint32_t tile_base, uint32_t (&ra)[E], uint32_t (&rb)[E]) {
 		if (FIRST) {
-			ra[0] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 4u * (uint32_t)lane, dmax));
-			ra[1] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 256u, dmax));
+#pragma unroll
+			for (int d = 0; d < ND; d++) ra[d] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 256u * d + 4u * (uint32_t)lane, dmax));
+			ra[ND] = *reinterpret_cast<const uint32_t *>(in + min(tile_base + 256u * ND, dmax));  // the dword after the tile, the same in every lane
 #pragma unroll
 			for (int e = 0; e < E; e++) rb[e] = compact ? a.run_len[base + min(tile_base + (uint32_t)(e * 64 + lane), last)] : 0u;  // see finish
 		} else {
@@ -191,10 +193,13 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 		for (int e = 0; e < E; e++) {
 			const uint32_t idx = tile_base + (uint32_t)(e * 64 + lane);
 			if (FIRST) {
-				const int la = e * 16 + (lane >> 2);  // lane holding the dword of byte idx
-				const uint32_t da = (uint32_t)__builtin_amdgcn_ds_bpermute(la << 2, (int)ra[0]);
-				uint32_t db = (uint32_t)__builtin_amdgcn_ds_bpermute(((la + 1) & 63) << 2, (int)ra[0]);
-				if (la == 63) db = ra[1];
+				const int la = (e & 3) * 16 + (lane >> 2);  // lane holding the dword of byte idx, in register e / 4
+				const uint32_t da = (uint32_t)__builtin_amdgcn_ds_bpermute(la << 2, (int)ra[e >> 2]);
+				uint32_t db = (uint32_t)__builtin_amdgcn_ds_bpermute(((la + 1) & 63) << 2, (int)ra[e >> 2]);
+				if ((e & 3) == 3) {  // the last lanes take the next dword from the next register's lane 0 (or from the dword after the tile)
+					const uint32_t nxt = (e >> 2) + 1 < ND ? (uint32_t)__builtin_amdgcn_readfirstlane((int)ra[(e >> 2) + 1 < ND ? (e >> 2) + 1 : 0]) : ra[ND];
+					if (la == 63) db = nxt;
+				}
 				const uint32_t sh = (uint32_t)lane & 3u;
 				const uint32_t w = __builtin_amdgcn_alignbyte(db, da, sh);  // bytes idx .. idx + 3
 				const uint32_t b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u;
