@@ -148,7 +148,9 @@ __global__ void __launch_bounds__(1024) dfl_sort_pass_kernel(DeflateArgs a)
 	// 64 (running per-digit counts in its own LDS row), so the cross-wave prefix and its two barriers are paid
 	// once per 4096 elements.  Loads of the next tile are issued before the current one is ranked.
 #ifndef CCT_SORT_E
-#define CCT_SORT_E 8  // pass B per batch: 2: 366, 4: 359, 8: 330-343 us; 12 spills (1318 us)
+#define CCT_SORT_E 4  // pass B alone, per batch: 2: 366, 4: 359, 8: 330-343 us, 12 spills (1318 us) -- but with 8 the kernel needs 116
+                      // VGPRs, a CU no longer holds its 16 waves next to an INFLATE workgroup, and in the pipelined bench the DEFLATE pass
+                      // took 4.67 instead of 3.5 ms (13.3 K instead of 17.4 K MPixels/s): 4 (72 VGPRs)
 #endif
 	constexpr int E = CCT_SORT_E;
 	constexpr int ND = E / 4;  // pass A: input dwords per lane (a wave's tile = 64 E positions = 16 E dwords)
