@@ -48,7 +48,10 @@ struct Geo {
 #define GEO_CONSTANTS constexpr int NT = G::NT, NWV = G::NWV, INF_IN = G::INF_IN, ROUND_OUT_BUDGET = G::ROUND_OUT_BUDGET; (void)NT; (void)NWV; (void)INF_IN; (void)ROUND_OUT_BUDGET
 constexpr int INF_RING = 65536, INF_RMASK = INF_RING - 1, INF_FLUSH = 4096;
 constexpr int INF_CHUNK = 4096;
-constexpr int LL_BITS = 12;
+#ifndef CCT_INF_LL_BITS
+#define CCT_INF_LL_BITS 12
+#endif
+constexpr int LL_BITS = CCT_INF_LL_BITS;
 constexpr int D_BITS = 10;
 constexpr uint32_t K_LIT = 1u << 24, K_LEN = 2u << 24, K_EOB = 3u << 24, K_TWO = 1u << 26;
 #ifndef CCT_INF_SEG_BITS
@@ -343,7 +346,10 @@ __device__ __forceinline__ uint32_t lane_pos(const LaneBits &lb, uint32_t org_dw
 // whose next symbol is not a literal simply does not move) for every general step.  The landing position must not depend
 // on how a lane got there (restarts compare landings): the second literal of a pair is taken only if it starts before
 // `end`, which makes the landing the first symbol boundary at or after `end` whatever the pairing.
-constexpr int FAST_STEPS = 3;
+#ifndef CCT_INF_FAST_STEPS
+#define CCT_INF_FAST_STEPS 3
+#endif
+constexpr int FAST_STEPS = CCT_INF_FAST_STEPS;
 template <bool EMIT, class G>
 __device__ __forceinline__ void walk_segment(InfShared<G> &S, uint32_t org_dword, uint32_t start, uint32_t end, uint32_t &land,
                                              uint32_t &nbytes, uint32_t &nmatch, uint32_t &flags, uint32_t o, uint32_t mi,
